@@ -1,0 +1,123 @@
+"""Synthetic GP model, DLA samples and quasar spectra of the shapes BASELINE.json names.
+
+There is no SDSS data in the build container or on the GPU box, so tests and ``bench.py`` use the
+generator specified in SURVEY.md section 8(d): a smooth mean, k orthonormal cosine modes with
+geometric scales, Halton (z-offset, log N_HI) samples, and spectra drawn from the model with a DLA
+injected into half of them.  Everything is seeded, so the oracle and the HIP path see identical
+inputs.  The shapes mirror the reference's files: the model fields of learn_qso_model.m:113-123,
+the samples of generate_dla_samples.m:59-63 and the ragged per-quasar arrays of
+preload_qsos.m:64-79.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .parameters import Parameters
+
+MODEL_SEED = 12345
+SPECTRUM_SEED0 = 20260101
+
+
+def halton(n: int, base: int) -> np.ndarray:
+    """Plain (unscrambled) Halton sequence, points 1..n."""
+    out = np.zeros(n)
+    for i in range(n):
+        f, r, j = 1.0, 0.0, i + 1
+        while j > 0:
+            f /= base
+            r += f * (j % base)
+            j //= base
+        out[i] = r
+    return out
+
+
+def make_model(k: int = 20, params: Parameters | None = None) -> dict:
+    p = params or Parameters()
+    rng = np.random.default_rng(MODEL_SEED)
+    G = int(round((p.max_lambda - p.min_lambda) / p.dlambda)) + 1  # 1217, learn_qso_model.m:29
+    rest = p.min_lambda + p.dlambda * np.arange(G)
+    u = (rest - rest[0]) / (rest[-1] - rest[0])
+    mu = (1.0 + 0.3 * np.exp(-0.5 * ((u - 0.95) / 0.08) ** 2)
+          + 0.1 * np.exp(-0.5 * ((u - 0.38) / 0.03) ** 2))
+    modes = np.cos(np.pi * (np.arange(G)[:, None] + 0.5) * (np.arange(k)[None, :] + 1) / G)
+    modes *= np.sqrt(2.0 / G)  # orthonormal columns
+    M = modes * (0.3 * 0.8 ** np.arange(k))[None, :] * np.sqrt(G) * 0.25
+    log_omega = rng.uniform(-3.0, -2.0, size=G)
+    return dict(rest_wavelengths=rest, mu=mu, M=np.asfortranarray(M), log_omega=log_omega,
+                log_c_0=float(np.log(0.1)), log_tau_0=float(np.log(0.0023)),
+                log_beta=float(np.log(3.65)))
+
+
+def make_samples(num_samples: int = 10000) -> dict:
+    offset = halton(num_samples, 2)
+    log_nhi = 20.0 + 3.0 * halton(num_samples, 3)
+    lls_log_nhi = 19.5 + 0.5 * halton(num_samples, 5)  # set_lls_parameters.m:59-63 range
+    return dict(offset_samples=offset, log_nhi_samples=log_nhi, nhi_samples=10.0 ** log_nhi,
+                lls_log_nhi_samples=lls_log_nhi, lls_nhi_samples=10.0 ** lls_log_nhi)
+
+
+def _injected_absorption(wavelengths, z_dla, nhi, num_lines):
+    # raw (un-broadened) Lyman-series profile, for data synthesis only
+    from scipy.special import wofz
+
+    from ._lyman import C_CGS, LINES, SIGMA_CGS
+    total = np.zeros_like(wavelengths)
+    for j in range(num_lines):
+        wl, lead, gam = LINES[j][0], LINES[j][3], LINES[j][4]
+        v = wavelengths * (C_CGS / (wl * (1 + z_dla)) / 1e8) - C_CGS
+        zc = (v + 1j * gam) / (np.sqrt(2) * SIGMA_CGS)
+        total += -lead * np.real(wofz(zc)) / (np.sqrt(2 * np.pi) * SIGMA_CGS)
+    return np.exp(nhi * total)
+
+
+def make_spectrum(index: int, n: int, model: dict, params: Parameters | None = None,
+                  mask_fraction: float = 0.0, edge_pixels: int = 2) -> dict:
+    """One synthetic quasar with exactly ``n`` pixels inside the modelled rest range (plus
+    ``edge_pixels`` outside on each side so the range test of process_qsos.m:104-105 is
+    exercised)."""
+    p = params or Parameters()
+    rng = np.random.default_rng(SPECTRUM_SEED0 + index)
+    z_qso = float(rng.uniform(2.2, 4.5))
+    span = np.log10(p.max_lambda / p.min_lambda)
+    dlog = span / n
+    idx = np.arange(-edge_pixels, n + edge_pixels)
+    log_wl = np.log10(p.min_lambda * (1 + z_qso)) + (idx + 0.5) * dlog
+    wl = 10.0 ** log_wl
+    rest = wl / (1 + z_qso)
+    k = model["M"].shape[1]
+    grid = model["rest_wavelengths"]
+    mu = np.interp(rest, grid, model["mu"])
+    Mi = np.stack([np.interp(rest, grid, model["M"][:, c]) for c in range(k)], 1)
+    omega2 = np.exp(2 * np.interp(rest, grid, model["log_omega"]))
+    nv = 10.0 ** rng.uniform(-3.0, -1.0, size=wl.size)
+    flux = (mu + Mi @ rng.standard_normal(k)
+            + np.sqrt(omega2 * 0.04 + nv) * rng.standard_normal(wl.size))
+    has_dla = bool(index % 2)
+    z_dla = log_nhi = None
+    if has_dla:
+        zmin = p.min_z_dla(wl, z_qso)
+        zmax = p.max_z_dla(wl, z_qso)
+        z_dla = float(rng.uniform(zmin, zmax))
+        log_nhi = float(rng.uniform(20.0, 22.0))
+        flux = flux * _injected_absorption(wl, z_dla, 10.0 ** log_nhi, p.num_lines)
+    mask = np.zeros(wl.size, dtype=np.uint8)
+    if mask_fraction > 0:
+        mask = (rng.uniform(size=wl.size) < mask_fraction).astype(np.uint8)
+        # masked pixels look like preload_qsos.m's: zero inverse variance -> infinite variance
+        nv = np.where(mask == 1, np.inf, nv)
+        flux = np.where(mask == 1, np.nan, flux)
+    return dict(wavelengths=wl, flux=flux, noise_variance=nv, pixel_mask=mask, z_qso=z_qso,
+                true_z_dla=z_dla, true_log_nhi=log_nhi)
+
+
+def make_spectra(num: int, n: int, model: dict, params: Parameters | None = None,
+                 mask_fraction: float = 0.0, first_index: int = 0) -> list:
+    return [make_spectrum(first_index + i, n, model, params, mask_fraction) for i in range(num)]
+
+
+def make_prior_catalog(num: int = 5000, seed: int = 777) -> dict:
+    """A stand-in for the training-catalog fields process_qsos.m:11-27 reads."""
+    rng = np.random.default_rng(seed)
+    z_qsos = rng.uniform(2.15, 5.0, size=num)
+    dla_ind = rng.uniform(size=num) < 0.1
+    return dict(z_qsos=z_qsos, dla_ind=dla_ind)
