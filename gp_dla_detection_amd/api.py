@@ -1,0 +1,318 @@
+"""Python host side of the MI355X inference sweep: the reference's call surface over libgpdla.so.
+
+Mirrors, name for name, what a user of jibanCat/gp_dla_detection calls on this path:
+
+=========================================  =====================================================
+reference                                  here
+=========================================  =====================================================
+``voigt(lambdas, z, N, num_lines)`` MEX    :func:`voigt`                      (voigt.c:253-304)
+``log_mvnpdf_low_rank(y, mu, M, d)``       :func:`log_mvnpdf_low_rank`        (log_mvnpdf_low_rank.m:5)
+DLA-existence prior of the driver          :func:`dla_existence_prior`        (process_qsos.m:122-131)
+``process_qsos`` script                    :func:`process_qsos`               (process_qsos.m:88-244)
+=========================================  =====================================================
+
+plus :class:`Context` / :class:`Batch` for callers that keep spectra resident in HBM (what
+``bench.py`` times, and what the multi-GPU driver in :mod:`.distributed` uses).  NumPy arrays and
+PyTorch-ROCm tensors are staging only; all arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .parameters import Parameters
+
+_dp = C.POINTER(C.c_double)
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _config(params: Parameters) -> _lib.Config:
+    lib = _lib.load()
+    cfg = _lib.Config()
+    lib.gpdla_default_config(C.byref(cfg))
+    for name in ("min_lambda", "max_lambda", "lya_wavelength", "lyman_limit", "pixel_spacing",
+                 "max_z_cut", "min_z_cut", "width", "num_lines"):
+        setattr(cfg, name, getattr(params, name))
+    for name in ("max_dlas", "num_forest_lines", "min_z_separation", "prev_tau_0", "prev_beta"):
+        if hasattr(params, name):
+            setattr(cfg, name, getattr(params, name))
+    return cfg
+
+
+# ----------------------------------------------------------------------------------------------
+# stand-alone surfaces
+# ----------------------------------------------------------------------------------------------
+
+def voigt(lambdas, z, N, num_lines: int = 31, device: int = 0) -> np.ndarray:
+    """``profile = voigt(lambdas, z, N[, num_lines])`` -- voigt.c:253-304.
+
+    Returns ``numel(lambdas) - 6`` values (the MEX trims ``width = 3`` pixels per side, :271).
+    ``num_lines`` defaults to 31 like the MEX (:16, :266)."""
+    lib = _lib.load()
+    lam, lp = _f64(lambdas)
+    if lam.size <= 6:
+        raise _lib.GpdlaError(-1, "lambdas must have more than 2*width = 6 entries")
+    out = np.empty(lam.size - 6)
+    _lib.check(lib.gpdla_voigt(lp, lam.size, float(z), float(N), int(num_lines),
+                               out.ctypes.data_as(_dp), int(device)))
+    return out
+
+
+def log_mvnpdf_low_rank(y, mu, M, d, device: int = 0) -> float:
+    """``log_p = log_mvnpdf_low_rank(y, mu, M, d)`` -- log N(y; mu, M M' + diag(d))
+    (log_mvnpdf_low_rank.m:5-34).  ``M`` is (n, k).  Raises GpdlaError(-4) where MATLAB's
+    ``chol`` would throw (:24)."""
+    lib = _lib.load()
+    y, yp = _f64(y)
+    mu, mup = _f64(mu)
+    d, dp = _f64(d)
+    Mf = np.asfortranarray(M, dtype=np.float64)
+    if Mf.ndim != 2 or Mf.shape[0] != y.size or mu.size != y.size or d.size != y.size:
+        raise _lib.GpdlaError(-1, "shape mismatch: y, mu, d are n-vectors and M is n x k")
+    out = C.c_double()
+    _lib.check(lib.gpdla_log_mvnpdf_low_rank(yp, mup, Mf.ctypes.data_as(_dp), dp, y.size,
+                                             Mf.shape[1], C.byref(out), int(device)))
+    return out.value
+
+
+def dla_existence_prior(prior_z_qsos, prior_dla_ind, z_qsos, params: Parameters | None = None):
+    """process_qsos.m:122-131: log p(DLA | z_QSO) and log p(no DLA | z_QSO) from the counts of
+    training-catalog quasars with z < z_QSO + prior_z_qso_increase.  Host logic (SURVEY.md
+    section 8a row A3)."""
+    p = params or Parameters()
+    pz = np.asarray(prior_z_qsos, dtype=np.float64)
+    pd = np.asarray(prior_dla_ind, dtype=bool)
+    z = np.atleast_1d(np.asarray(z_qsos, dtype=np.float64))
+    order = np.argsort(pz, kind="stable")
+    pz_sorted = pz[order]
+    cum_dla = np.concatenate([[0], np.cumsum(pd[order])])
+    num_quasars = np.searchsorted(pz_sorted, z + p.prior_z_qso_increase, side="left")  # strict <
+    num_dlas = cum_dla[num_quasars]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log_dla = np.log(num_dlas.astype(np.float64)) - np.log(num_quasars.astype(np.float64))
+        log_no = (np.log((num_quasars - num_dlas).astype(np.float64))
+                  - np.log(num_quasars.astype(np.float64)))
+    return log_no, log_dla
+
+
+# ----------------------------------------------------------------------------------------------
+# resident form
+# ----------------------------------------------------------------------------------------------
+
+class _DeviceArray:
+    """Zero-copy view of library-owned HBM for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr: int, shape, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": "<f8",
+                                         "data": (int(ptr), False), "version": 2}
+        self._owner = owner  # keeps the batch alive
+
+
+def spectra_to_csr(spectra):
+    """The ragged cell arrays of preloaded_qsos.mat (preload_qsos.m:64-79) as flat CSR arrays."""
+    sizes = [np.asarray(s["wavelengths"]).size for s in spectra]
+    offsets = np.zeros(len(spectra) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offsets[1:])
+    cat = lambda key, dt: (np.concatenate([np.asarray(s[key], dtype=dt).ravel() for s in spectra])
+                           if spectra else np.zeros(0, dt))
+    return dict(offsets=offsets, wavelengths=cat("wavelengths", np.float64),
+                flux=cat("flux", np.float64), noise_variance=cat("noise_variance", np.float64),
+                pixel_mask=cat("pixel_mask", np.uint8),
+                z_qsos=np.array([float(s["z_qso"]) for s in spectra], dtype=np.float64))
+
+
+class Context:
+    """A device + stream + the replicated GP model and DLA samples (gpdla_context)."""
+
+    def __init__(self, device: int = 0, params: Parameters | None = None, stream=None):
+        self.lib = _lib.load()
+        self.device = int(device)
+        self.params = params or Parameters()
+        self._h = C.c_void_p()
+        _lib.check(self.lib.gpdla_context_create(self.device, C.byref(self._h)))
+        cfg = _config(self.params)
+        _lib.check(self.lib.gpdla_context_set_config(self._h, C.byref(cfg)))
+        if stream is not None:
+            self.set_stream(stream)
+        self.num_samples = 0
+        self.k = 0
+
+    def set_stream(self, stream):
+        """``stream``: a raw hipStream_t (int) or a torch.cuda.Stream."""
+        ptr = getattr(stream, "cuda_stream", stream)
+        _lib.check(self.lib.gpdla_context_set_stream(self._h, C.c_void_p(int(ptr) if ptr else None)))
+
+    def set_model(self, model: dict):
+        """Fields of learned_qso_model_*.mat (process_qsos.m:30-35)."""
+        rw, rwp = _f64(model["rest_wavelengths"])
+        mu, mup = _f64(model["mu"])
+        Mf = np.asfortranarray(model["M"], dtype=np.float64)
+        lo, lop = _f64(model["log_omega"])
+        m = _lib.Model(rw.size, Mf.shape[1], rwp, mup, Mf.ctypes.data_as(_dp), lop,
+                       float(model["log_c_0"]), float(model["log_tau_0"]), float(model["log_beta"]))
+        _lib.check(self.lib.gpdla_context_set_model(self._h, C.byref(m)))
+        self.k = Mf.shape[1]
+
+    def set_samples(self, samples: dict):
+        """Fields of dla_samples.mat (process_qsos.m:38-40)."""
+        off, offp = _f64(samples["offset_samples"])
+        nhi, nhip = _f64(samples["nhi_samples"])
+        keep = [off, nhi]
+        lnp = llp = None
+        if samples.get("log_nhi_samples") is not None:
+            a, lnp = _f64(samples["log_nhi_samples"])
+            keep.append(a)
+        if samples.get("lls_nhi_samples") is not None:
+            a, llp = _f64(samples["lls_nhi_samples"])
+            keep.append(a)
+        s = _lib.Samples(off.size, offp, lnp, nhip, llp)
+        _lib.check(self.lib.gpdla_context_set_samples(self._h, C.byref(s)))
+        self.num_samples = off.size
+
+    def set_timing(self, enabled: bool):
+        _lib.check(self.lib.gpdla_context_set_timing(self._h, int(bool(enabled))))
+
+    def last_sweep_ms(self) -> float:
+        return float(self.lib.gpdla_context_last_sweep_ms(self._h))
+
+    def synchronize(self):
+        _lib.check(self.lib.gpdla_context_synchronize(self._h))
+
+    def upload(self, spectra, log_priors_no_dla, log_priors_dla) -> "Batch":
+        return Batch(self, spectra, log_priors_no_dla, log_priors_dla)
+
+    def close(self):
+        if self._h:
+            self.lib.gpdla_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """A CSR batch of spectra resident in HBM together with its result tables (gpdla_batch)."""
+
+    def __init__(self, ctx: Context, spectra, log_priors_no_dla, log_priors_dla):
+        self.ctx = ctx
+        csr = spectra if isinstance(spectra, dict) else spectra_to_csr(spectra)
+        self.num_quasars = csr["z_qsos"].size
+        self.num_samples = ctx.num_samples
+        keep = []
+
+        def ptr(a, dt, ct):
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(ct))
+
+        sp = _lib.Spectra(
+            self.num_quasars, ptr(csr["offsets"], np.int64, C.c_int64),
+            ptr(csr["wavelengths"], np.float64, C.c_double), ptr(csr["flux"], np.float64, C.c_double),
+            ptr(csr["noise_variance"], np.float64, C.c_double),
+            ptr(csr["pixel_mask"], np.uint8, C.c_uint8), ptr(csr["z_qsos"], np.float64, C.c_double),
+            ptr(log_priors_no_dla, np.float64, C.c_double),
+            ptr(log_priors_dla, np.float64, C.c_double), None)
+        self._h = C.c_void_p()
+        _lib.check(ctx.lib.gpdla_batch_upload(ctx._h, C.byref(sp), C.byref(self._h)))
+        self.log_priors_no_dla = np.array(log_priors_no_dla, dtype=np.float64)
+        self.log_priors_dla = np.array(log_priors_dla, dtype=np.float64)
+
+    def process(self):
+        """Launch the sweep for every quasar of the batch (asynchronous on the context's stream)."""
+        _lib.check(self.ctx.lib.gpdla_batch_process(self.ctx._h, self._h))
+
+    def download(self, with_samples: bool = True) -> dict:
+        """Results under the field names process_qsos.m:236-244 saves."""
+        nq, S = self.num_quasars, self.num_samples
+        out = {name: np.full(nq, np.nan) for name in (
+            "min_z_dlas", "max_z_dlas", "log_likelihoods_no_dla", "log_likelihoods_dla",
+            "log_posteriors_no_dla", "log_posteriors_dla", "p_no_dlas", "p_dlas")}
+        out["model_posteriors"] = np.full((nq, 2), np.nan)
+        out["status"] = np.zeros(nq, dtype=np.int32)
+        if with_samples:
+            out["sample_log_likelihoods_dla"] = np.full((nq, S), np.nan)
+        r = _lib.Results()
+        for name, _ in _lib.Results._fields_:
+            if name in out:
+                ct = C.c_int32 if name == "status" else C.c_double
+                setattr(r, name, out[name].ctypes.data_as(C.POINTER(ct)))
+        _lib.check(self.ctx.lib.gpdla_batch_download(self.ctx._h, self._h, C.byref(r)))
+        out["log_priors_no_dla"] = self.log_priors_no_dla
+        out["log_priors_dla"] = self.log_priors_dla
+        return out
+
+    def summary_tensor(self):
+        """The [nq, 12] per-quasar summary table as a zero-copy torch tensor on this GPU."""
+        import torch
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.ctx.lib.gpdla_batch_summary_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DeviceArray(p.value, (n.value, 12), self),
+                               device=f"cuda:{self.ctx.device}")
+
+    def samples_tensor(self):
+        """sample_log_likelihoods_dla [nq, S] as a zero-copy torch tensor on this GPU."""
+        import torch
+        p, n, s = C.c_void_p(), C.c_int64(), C.c_int64()
+        _lib.check(self.ctx.lib.gpdla_batch_samples_device_ptr(self._h, C.byref(p), C.byref(n),
+                                                               C.byref(s)))
+        return torch.as_tensor(_DeviceArray(p.value, (n.value, s.value), self),
+                               device=f"cuda:{self.ctx.device}")
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.gpdla_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------
+# the script surface
+# ----------------------------------------------------------------------------------------------
+
+def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None = None,
+                 params: Parameters | None = None, device: int = 0,
+                 log_priors: tuple | None = None) -> dict:
+    """The ``process_qsos`` script (process_qsos.m:4-250) for a list of quasars.
+
+    ``spectra``: list of dicts with ``wavelengths, flux, noise_variance, pixel_mask, z_qso`` (one
+    entry of the ``all_*`` cell arrays each, after the ``test_ind`` subset of :56-61).
+    ``prior_catalog``: ``{"z_qsos", "dla_ind"}`` of the training release after the Lyman-limit
+    filter of :15-25; or pass ``log_priors=(log_priors_no_dla, log_priors_dla)`` directly.
+    Returns the variables the script saves (:236-244)."""
+    p = params or Parameters()
+    csr = spectra_to_csr(spectra)
+    if log_priors is None:
+        if prior_catalog is None:
+            raise ValueError("need prior_catalog or log_priors")
+        log_priors = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"],
+                                         csr["z_qsos"], p)
+    ctx = Context(device, p)
+    try:
+        ctx.set_model(model)
+        ctx.set_samples(samples)
+        batch = ctx.upload(csr, log_priors[0], log_priors[1])
+        try:
+            batch.process()
+            out = batch.download()
+        finally:
+            batch.close()
+    finally:
+        ctx.close()
+    out["num_lines"] = p.num_lines
+    out["prior_z_qso_increase"] = p.prior_z_qso_increase
+    out["max_z_cut"] = p.max_z_cut
+    return out

@@ -1,0 +1,677 @@
+// gpdla.hip -- host side of libgpdla.so: the C-ABI of include/gpdla.h over the HIP kernels in
+// sweep_kernels.hpp.  No torch types, no CPU compute path: if the device is missing every compute
+// entry point fails with GPDLA_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/gpdla.h"
+#include "../../include/gpdla_lyman_series.h"
+#include "sweep_kernels.hpp"
+
+using namespace gpdla;
+
+namespace {
+
+thread_local std::string t_error = "";
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  t_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(GPDLA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                  __FILE__, __LINE__);                                                     \
+  } while (0)
+
+int select_device(int device_id) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(GPDLA_ERR_NO_DEVICE, "no HIP device available (%s); libgpdla has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n)
+    return fail(GPDLA_ERR_NO_DEVICE, "device_id %d out of range [0, %d)", device_id, n);
+  HIP_TRY(hipSetDevice(device_id));
+  return GPDLA_OK;
+}
+
+// Lyman-series tables -> __constant__ memory, once per device.
+std::mutex g_table_mutex;
+bool g_table_loaded[64] = {false};
+
+int ensure_line_table(int device_id) {
+  std::lock_guard<std::mutex> lock(g_table_mutex);
+  if (device_id < 64 && g_table_loaded[device_id]) return GPDLA_OK;
+  LineTable t;
+#define GP_WL(i, wl, f, G, lead, gam) wl,
+#define GP_LEAD(i, wl, f, G, lead, gam) lead,
+#define GP_GAM(i, wl, f, G, lead, gam) gam,
+  const double wl[] = {GPDLA_LYMAN_SERIES(GP_WL)};
+  const double lead[] = {GPDLA_LYMAN_SERIES(GP_LEAD)};
+  const double gam[] = {GPDLA_LYMAN_SERIES(GP_GAM)};
+  const double taps[] = GPDLA_INSTRUMENT_PROFILE;
+  const double sigma = GPDLA_GAUSS_SIGMA_CGS;
+  for (int i = 0; i < kMaxLines; ++i) {
+    t.wavelength_cm[i] = wl[i];
+    t.leading[i] = lead[i];
+    t.y[i] = gam[i] / std::sqrt(2.0) / sigma;
+  }
+  for (int i = 0; i < 7; ++i) t.taps[i] = taps[i];
+  t.c = GPDLA_SPEED_OF_LIGHT_CGS;
+  t.inv_sqrt2_sigma = 1.0 / (std::sqrt(2.0) * sigma);
+  t.inv_sqrt2pi_sigma = 1.0 / (std::sqrt(2.0 * 3.14159265358979323846) * sigma);
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lines), &t, sizeof(t)));
+  if (device_id < 64) g_table_loaded[device_id] = true;
+  return GPDLA_OK;
+}
+
+template <typename T>
+int dev_alloc(T **p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+  return GPDLA_OK;
+}
+
+template <typename T>
+int upload(T **p, const T *host, size_t count, hipStream_t st) {
+  int rc = dev_alloc(p, count);
+  if (rc) return rc;
+  if (count) HIP_TRY(hipMemcpyAsync(*p, host, count * sizeof(T), hipMemcpyHostToDevice, st));
+  return GPDLA_OK;
+}
+
+void dev_free(void *p) {
+  if (p) (void)hipFree(p);
+}
+
+}  // namespace
+
+struct gpdla_context {
+  int device_id = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  // model
+  bool has_model = false;
+  ModelDev model{};
+  double *d_rest = nullptr, *d_mu = nullptr, *d_M = nullptr, *d_log_omega = nullptr;
+  // samples
+  bool has_samples = false;
+  int64_t S = 0;
+  double *d_offset = nullptr, *d_nhi = nullptr, *d_log_nhi = nullptr, *d_lls_nhi = nullptr;
+  int32_t *d_perm = nullptr;
+  gpdla_config cfg{};
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool have_timing = false;
+};
+
+struct gpdla_batch {
+  gpdla_context *ctx = nullptr;
+  int64_t nq = 0, S = 0, total_pix = 0;
+  int64_t *d_offsets = nullptr;
+  double *d_wl = nullptr, *d_flux = nullptr, *d_nv = nullptr, *d_z = nullptr;
+  uint8_t *d_mask = nullptr;
+  double *d_lp_no = nullptr, *d_lp_dla = nullptr;
+  QuasarMeta *d_meta = nullptr;
+  PixelRow *d_pix = nullptr;
+  double *d_Mi = nullptr, *d_lam = nullptr, *d_pm = nullptr;
+  double *d_sample_ll = nullptr, *d_ll_no = nullptr, *d_summary = nullptr;
+  int64_t pool_rows = 0;
+  int32_t k = 0, tiles_w = 0, ntiles = 0;
+};
+
+extern "C" {
+
+int gpdla_abi_version(void) { return GPDLA_ABI_VERSION; }
+
+const char *gpdla_last_error(void) { return t_error.c_str(); }
+
+void gpdla_default_config(gpdla_config *cfg) {
+  if (!cfg) return;
+  const double kms = 1000.0 / 299792458.0;  // set_parameters.m:8, :11
+  cfg->min_lambda = 911.75;                 // :33
+  cfg->max_lambda = 1215.75;                // :34
+  cfg->lya_wavelength = 1215.6701;          // :5
+  cfg->lyman_limit = 911.7633;              // :7
+  cfg->pixel_spacing = 1e-4;                // :60
+  cfg->max_z_cut = 3000 * kms;              // :65
+  cfg->min_z_cut = 3000 * kms;              // :69
+  cfg->width = 3;                           // :59
+  cfg->num_lines = 3;                       // :63
+  cfg->max_dlas = 4;                        // process_qsos_multiple_dlas_meanflux.m:32
+  cfg->num_forest_lines = 31;               // set_parameters_multi.m:75
+  cfg->min_z_separation = 3000 * kms;       // multi :33
+  cfg->prev_tau_0 = 0.0023;                 // multi :36
+  cfg->prev_beta = 3.65;                    // multi :37
+}
+
+/* ------------------------------ context ------------------------------ */
+
+int gpdla_context_create(int device_id, gpdla_context **out) {
+  if (!out) return fail(GPDLA_ERR_INVALID_ARGUMENT, "ctx out pointer is null");
+  *out = nullptr;
+  int rc = select_device(device_id);
+  if (rc) return rc;
+  rc = ensure_line_table(device_id);
+  if (rc) return rc;
+  gpdla_context *c = new gpdla_context();
+  c->device_id = device_id;
+  HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  gpdla_default_config(&c->cfg);
+  *out = c;
+  return GPDLA_OK;
+}
+
+void gpdla_context_destroy(gpdla_context *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device_id);
+  (void)hipStreamSynchronize(c->stream);
+  dev_free(c->d_rest);
+  dev_free(c->d_mu);
+  dev_free(c->d_M);
+  dev_free(c->d_log_omega);
+  dev_free(c->d_offset);
+  dev_free(c->d_nhi);
+  dev_free(c->d_log_nhi);
+  dev_free(c->d_lls_nhi);
+  dev_free(c->d_perm);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int gpdla_context_set_stream(gpdla_context *c, void *hip_stream) {
+  if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return GPDLA_OK;
+}
+
+int gpdla_context_set_config(gpdla_context *c, const gpdla_config *cfg) {
+  if (!c || !cfg) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context/config");
+  if (cfg->width != 3)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "width must be 3 (voigt.c:229 hard-codes the 7-tap profile)");
+  if (cfg->num_lines < 1 || cfg->num_lines > kMaxLines)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "num_lines %d outside [1, 31]", cfg->num_lines);
+  c->cfg = *cfg;
+  return GPDLA_OK;
+}
+
+int gpdla_context_synchronize(gpdla_context *c) {
+  if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
+  HIP_TRY(hipSetDevice(c->device_id));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return GPDLA_OK;
+}
+
+int gpdla_context_set_model(gpdla_context *c, const gpdla_model *m) {
+  if (!c || !m || !m->rest_wavelengths || !m->mu || !m->M || !m->log_omega)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null model field");
+  if (m->num_rest_pixels < 2 || m->k < 1)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "model needs >= 2 grid points and k >= 1");
+  if (m->k > GPDLA_MAX_K) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d > %d", m->k, GPDLA_MAX_K);
+  HIP_TRY(hipSetDevice(c->device_id));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  dev_free(c->d_rest);
+  dev_free(c->d_mu);
+  dev_free(c->d_M);
+  dev_free(c->d_log_omega);
+  const size_t G = (size_t)m->num_rest_pixels;
+  int rc;
+  if ((rc = upload(&c->d_rest, m->rest_wavelengths, G, c->stream))) return rc;
+  if ((rc = upload(&c->d_mu, m->mu, G, c->stream))) return rc;
+  if ((rc = upload(&c->d_M, m->M, G * m->k, c->stream))) return rc;
+  if ((rc = upload(&c->d_log_omega, m->log_omega, G, c->stream))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->model.G = m->num_rest_pixels;
+  c->model.k = m->k;
+  c->model.rest = c->d_rest;
+  c->model.mu = c->d_mu;
+  c->model.M = c->d_M;
+  c->model.log_omega = c->d_log_omega;
+  c->model.c_0 = std::exp(m->log_c_0);      // process_qsos.m:84-86
+  c->model.tau_0 = std::exp(m->log_tau_0);
+  c->model.beta = std::exp(m->log_beta);
+  c->has_model = true;
+  return GPDLA_OK;
+}
+
+int gpdla_context_set_samples(gpdla_context *c, const gpdla_samples *s) {
+  if (!c || !s || !s->offset_samples || !s->nhi_samples || s->num_dla_samples < 1)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty samples");
+  HIP_TRY(hipSetDevice(c->device_id));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  dev_free(c->d_offset);
+  dev_free(c->d_nhi);
+  dev_free(c->d_log_nhi);
+  dev_free(c->d_lls_nhi);
+  dev_free(c->d_perm);
+  c->d_log_nhi = c->d_lls_nhi = nullptr;
+  const size_t S = (size_t)s->num_dla_samples;
+  // visit samples in ascending z_DLA order: z = min + (max - min) * offset is monotone in offset
+  // for every quasar, so one permutation serves the whole run
+  std::vector<int32_t> perm(S);
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) {
+    return s->offset_samples[a] < s->offset_samples[b];
+  });
+  int rc;
+  if ((rc = upload(&c->d_offset, s->offset_samples, S, c->stream))) return rc;
+  if ((rc = upload(&c->d_nhi, s->nhi_samples, S, c->stream))) return rc;
+  if (s->log_nhi_samples && (rc = upload(&c->d_log_nhi, s->log_nhi_samples, S, c->stream))) return rc;
+  if (s->lls_nhi_samples && (rc = upload(&c->d_lls_nhi, s->lls_nhi_samples, S, c->stream))) return rc;
+  if ((rc = upload(&c->d_perm, perm.data(), S, c->stream))) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->S = (int64_t)S;
+  c->has_samples = true;
+  return GPDLA_OK;
+}
+
+int gpdla_context_set_timing(gpdla_context *c, int enabled) {
+  if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
+  HIP_TRY(hipSetDevice(c->device_id));
+  if (enabled && !c->ev0) {
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+  }
+  c->timing = enabled != 0;
+  c->have_timing = false;
+  return GPDLA_OK;
+}
+
+double gpdla_context_last_sweep_ms(gpdla_context *c) {
+  if (!c || !c->have_timing) return -1.0;
+  (void)hipSetDevice(c->device_id);
+  if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+/* ------------------------------ batch ------------------------------ */
+
+void gpdla_batch_destroy(gpdla_batch *b) {
+  if (!b) return;
+  if (b->ctx) {
+    (void)hipSetDevice(b->ctx->device_id);
+    (void)hipStreamSynchronize(b->ctx->stream);
+  }
+  dev_free(b->d_offsets);
+  dev_free(b->d_wl);
+  dev_free(b->d_flux);
+  dev_free(b->d_nv);
+  dev_free(b->d_z);
+  dev_free(b->d_mask);
+  dev_free(b->d_lp_no);
+  dev_free(b->d_lp_dla);
+  dev_free(b->d_meta);
+  dev_free(b->d_pix);
+  dev_free(b->d_Mi);
+  dev_free(b->d_lam);
+  dev_free(b->d_pm);
+  dev_free(b->d_sample_ll);
+  dev_free(b->d_ll_no);
+  dev_free(b->d_summary);
+  delete b;
+}
+
+int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **out) {
+  if (!c || !sp || !out) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (!c->has_model || !c->has_samples)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "set the model and the samples before uploading spectra");
+  if (sp->num_quasars < 1 || !sp->offsets || !sp->wavelengths || !sp->flux || !sp->noise_variance ||
+      !sp->pixel_mask || !sp->z_qsos || !sp->log_priors_no_dla || !sp->log_priors_dla)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
+  const int64_t nq = sp->num_quasars;
+  for (int64_t q = 0; q < nq; ++q)
+    if (sp->offsets[q + 1] < sp->offsets[q])
+      return fail(GPDLA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing (quasar %lld)", (long long)q);
+  HIP_TRY(hipSetDevice(c->device_id));
+  gpdla_batch *b = new gpdla_batch();
+  b->ctx = c;
+  b->nq = nq;
+  b->S = c->S;
+  b->k = c->model.k;
+  b->tiles_w = (b->k * (b->k + 1) / 2 + 15) / 16;
+  b->ntiles = b->tiles_w + (b->k + 15) / 16;
+  const int64_t base = sp->offsets[0];
+  b->total_pix = sp->offsets[nq] - base;
+  std::vector<int64_t> off(nq + 1);
+  std::vector<QuasarMeta> meta(nq);
+  int64_t rows = 0, lam = 0;
+  for (int64_t q = 0; q <= nq; ++q) off[q] = sp->offsets[q] - base;
+  for (int64_t q = 0; q < nq; ++q) {
+    const int64_t npix = off[q + 1] - off[q];
+    std::memset(&meta[q], 0, sizeof(QuasarMeta));
+    meta[q].status = 1;
+    meta[q].pix_off = rows;
+    meta[q].lam_off = lam;
+    rows += 4 * ((npix + 3) / 4) + 4;
+    lam += ((npix + 6 + 1) / 2) * 2 + 2;
+  }
+  b->pool_rows = rows;
+  hipStream_t st = c->stream;
+  int rc = GPDLA_OK;
+  auto chk = [&](int r) { if (r && !rc) rc = r; };
+  chk(upload(&b->d_offsets, off.data(), (size_t)nq + 1, st));
+  chk(upload(&b->d_wl, sp->wavelengths + base, (size_t)b->total_pix, st));
+  chk(upload(&b->d_flux, sp->flux + base, (size_t)b->total_pix, st));
+  chk(upload(&b->d_nv, sp->noise_variance + base, (size_t)b->total_pix, st));
+  chk(upload(&b->d_mask, sp->pixel_mask + base, (size_t)b->total_pix, st));
+  chk(upload(&b->d_z, sp->z_qsos, (size_t)nq, st));
+  chk(upload(&b->d_lp_no, sp->log_priors_no_dla, (size_t)nq, st));
+  chk(upload(&b->d_lp_dla, sp->log_priors_dla, (size_t)nq, st));
+  chk(upload(&b->d_meta, meta.data(), (size_t)nq, st));
+  chk(dev_alloc(&b->d_pix, (size_t)rows));
+  chk(dev_alloc(&b->d_Mi, (size_t)rows * b->k));
+  chk(dev_alloc(&b->d_lam, (size_t)lam));
+  chk(dev_alloc(&b->d_pm, (size_t)(rows / 4) * b->ntiles * 64));
+  chk(dev_alloc(&b->d_sample_ll, (size_t)nq * b->S));
+  chk(dev_alloc(&b->d_ll_no, (size_t)nq));
+  chk(dev_alloc(&b->d_summary, (size_t)nq * GPDLA_SUMMARY_COLS));
+  if (rc) {
+    gpdla_batch_destroy(b);
+    return rc;
+  }
+  // host vectors (off, meta) must outlive the async copies
+  if (hipStreamSynchronize(st) != hipSuccess) {
+    gpdla_batch_destroy(b);
+    return fail(GPDLA_ERR_HIP, "upload synchronize failed");
+  }
+  *out = b;
+  return GPDLA_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <int NTW, int TS>
+int launch_sweep(gpdla_context *c, gpdla_batch *b, const SweepArgs &args) {
+  constexpr int groups = kWavesPerBlock / TS;
+  const int L = args.num_lines;
+  const size_t loop_doubles = (size_t)kChunkSteps * b->ntiles * 64 +
+                              (size_t)kWavesPerBlock * kSamplesPerWave * kRingStride +
+                              (size_t)groups * kSamplesPerWave * L;
+  const size_t epi_doubles = (size_t)groups * b->ntiles * 16 * (kSamplesPerWave + 1);
+  const size_t lds = std::max(loop_doubles, epi_doubles) * sizeof(double);
+  if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "sweep needs %zu B of LDS", lds);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<NTW, TS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t nblocks = 8 * ((b->nq + 7) / 8) * (int64_t)args.blocks_per_quasar;
+  if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "batch too large for one launch");
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL((k_sweep<NTW, TS>), dim3((unsigned)nblocks), dim3(256), lds, c->stream, args);
+  HIP_TRY(hipGetLastError());
+  if (c->timing) {
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->have_timing = true;
+  }
+  return GPDLA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
+  if (!c || !b || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
+  if (b->S != c->S || b->k != c->model.k)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "model/samples changed after the batch was uploaded");
+  HIP_TRY(hipSetDevice(c->device_id));
+  hipStream_t st = c->stream;
+  Config cfg;
+  cfg.min_lambda = c->cfg.min_lambda;
+  cfg.max_lambda = c->cfg.max_lambda;
+  cfg.lya_wavelength = c->cfg.lya_wavelength;
+  cfg.lyman_limit = c->cfg.lyman_limit;
+  cfg.pixel_spacing = c->cfg.pixel_spacing;
+  cfg.max_z_cut = c->cfg.max_z_cut;
+  cfg.min_z_cut = c->cfg.min_z_cut;
+  cfg.num_lines = c->cfg.num_lines;
+
+  PrepareArgs pa;
+  pa.nq = b->nq;
+  pa.offsets = b->d_offsets;
+  pa.wavelengths = b->d_wl;
+  pa.flux = b->d_flux;
+  pa.noise_variance = b->d_nv;
+  pa.pixel_mask = b->d_mask;
+  pa.z_qsos = b->d_z;
+  pa.model = c->model;
+  pa.cfg = cfg;
+  pa.meta = b->d_meta;
+  pa.pix = b->d_pix;
+  pa.Mi = b->d_Mi;
+  pa.lam_pad = b->d_lam;
+  hipLaunchKernelGGL(k_prepare, dim3((unsigned)b->nq), dim3(256), 0, st, pa);
+  HIP_TRY(hipGetLastError());
+
+  BuildPmArgs ba;
+  ba.meta = b->d_meta;
+  ba.Mi = b->d_Mi;
+  ba.pm = b->d_pm;
+  ba.k = b->k;
+  ba.tiles_w = b->tiles_w;
+  ba.ntiles = b->ntiles;
+  ba.blocks_per_quasar = 16;
+  hipLaunchKernelGGL(k_build_pm, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
+  HIP_TRY(hipGetLastError());
+
+  // NaN pre-fill, as process_qsos.m:74-82 does for quasars that are skipped
+  HIP_TRY(hipMemsetAsync(b->d_sample_ll, 0xFF, (size_t)b->nq * b->S * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(b->d_ll_no, 0xFF, (size_t)b->nq * sizeof(double), st));
+
+  SweepArgs sa;
+  sa.meta = b->d_meta;
+  sa.pix = b->d_pix;
+  sa.lam_pad = b->d_lam;
+  sa.pm = b->d_pm;
+  sa.offset_samples = c->d_offset;
+  sa.nhi_samples = c->d_nhi;
+  sa.perm = c->d_perm;
+  sa.S = b->S;
+  sa.nq = b->nq;
+  sa.k = b->k;
+  sa.tiles_w = b->tiles_w;
+  sa.ntiles = b->ntiles;
+  sa.num_lines = cfg.num_lines;
+  sa.sample_ll = b->d_sample_ll;
+  sa.ll_no_dla = b->d_ll_no;
+  int rc;
+  if (b->ntiles <= 16) {
+    sa.blocks_per_quasar = (int32_t)((b->S + 1 + 63) / 64);
+    rc = launch_sweep<16, 1>(c, b, sa);
+  } else if (b->ntiles <= 56) {
+    sa.blocks_per_quasar = (int32_t)((b->S + 1 + 15) / 16);
+    rc = launch_sweep<14, 4>(c, b, sa);
+  } else {
+    rc = fail(GPDLA_ERR_UNSUPPORTED, "k = %d needs %d B tiles (max 56)", b->k, b->ntiles);
+  }
+  if (rc) return rc;
+
+  EvidenceArgs ea;
+  ea.meta = b->d_meta;
+  ea.sample_ll = b->d_sample_ll;
+  ea.ll_no_dla = b->d_ll_no;
+  ea.log_prior_no_dla = b->d_lp_no;
+  ea.log_prior_dla = b->d_lp_dla;
+  ea.S = b->S;
+  ea.summary = b->d_summary;
+  hipLaunchKernelGGL(k_evidence, dim3((unsigned)b->nq), dim3(256), 0, st, ea);
+  HIP_TRY(hipGetLastError());
+  return GPDLA_OK;
+}
+
+int gpdla_batch_summary_device_ptr(gpdla_batch *b, double **table, int64_t *nq) {
+  if (!b || !table) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  *table = b->d_summary;
+  if (nq) *nq = b->nq;
+  return GPDLA_OK;
+}
+
+int gpdla_batch_samples_device_ptr(gpdla_batch *b, double **table, int64_t *nq, int64_t *S) {
+  if (!b || !table) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  *table = b->d_sample_ll;
+  if (nq) *nq = b->nq;
+  if (S) *S = b->S;
+  return GPDLA_OK;
+}
+
+int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) {
+  if (!c || !b || !r || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched argument");
+  HIP_TRY(hipSetDevice(c->device_id));
+  const size_t nq = (size_t)b->nq;
+  std::vector<double> summary(nq * GPDLA_SUMMARY_COLS);
+  std::vector<QuasarMeta> meta(nq);
+  HIP_TRY(hipMemcpyAsync(summary.data(), b->d_summary, summary.size() * sizeof(double),
+                         hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(meta.data(), b->d_meta, nq * sizeof(QuasarMeta), hipMemcpyDeviceToHost, c->stream));
+  if (r->sample_log_likelihoods_dla)
+    HIP_TRY(hipMemcpyAsync(r->sample_log_likelihoods_dla, b->d_sample_ll, nq * b->S * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (size_t q = 0; q < nq; ++q) {
+    const double *s = &summary[q * GPDLA_SUMMARY_COLS];
+    if (r->min_z_dlas) r->min_z_dlas[q] = s[0];
+    if (r->max_z_dlas) r->max_z_dlas[q] = s[1];
+    if (r->log_likelihoods_no_dla) r->log_likelihoods_no_dla[q] = s[4];
+    if (r->log_likelihoods_dla) r->log_likelihoods_dla[q] = s[5];
+    if (r->log_posteriors_no_dla) r->log_posteriors_no_dla[q] = s[6];
+    if (r->log_posteriors_dla) r->log_posteriors_dla[q] = s[7];
+    if (r->model_posteriors) {
+      r->model_posteriors[2 * q] = s[8];
+      r->model_posteriors[2 * q + 1] = s[9];
+    }
+    if (r->p_no_dlas) r->p_no_dlas[q] = s[10];
+    if (r->p_dlas) r->p_dlas[q] = s[11];
+    if (r->status) r->status[q] = meta[q].status;
+  }
+  return GPDLA_OK;
+}
+
+int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
+                        const gpdla_spectra *spectra, const gpdla_config *config,
+                        gpdla_results *results, int device_id) {
+  if (!model || !samples || !spectra || !results)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  gpdla_context *c = nullptr;
+  gpdla_batch *b = nullptr;
+  int rc = gpdla_context_create(device_id, &c);
+  if (rc) return rc;
+  gpdla_config cfg;
+  gpdla_default_config(&cfg);
+  if (config) cfg = *config;
+  if (!(rc = gpdla_context_set_config(c, &cfg)) && !(rc = gpdla_context_set_model(c, model)) &&
+      !(rc = gpdla_context_set_samples(c, samples)) && !(rc = gpdla_batch_upload(c, spectra, &b)) &&
+      !(rc = gpdla_batch_process(c, b)))
+    rc = gpdla_batch_download(c, b, results);
+  gpdla_batch_destroy(b);
+  gpdla_context_destroy(c);
+  return rc;
+}
+
+/* ------------------------------ stand-alone surfaces ------------------------------ */
+
+int gpdla_voigt(const double *lambdas, int64_t n_padded, double z, double N, int num_lines,
+                double *profile_out, int device_id) {
+  if (!lambdas || !profile_out) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n_padded <= 6) return fail(GPDLA_ERR_INVALID_ARGUMENT, "n_padded = %lld must exceed 2*width = 6", (long long)n_padded);
+  if (num_lines < 1 || num_lines > kMaxLines)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "num_lines %d outside [1, 31]", num_lines);
+  int rc = select_device(device_id);
+  if (rc) return rc;
+  if ((rc = ensure_line_table(device_id))) return rc;
+  double *d_lam = nullptr, *d_raw = nullptr, *d_prof = nullptr;
+  const int64_t n_out = n_padded - 6;
+  auto cleanup = [&]() {
+    dev_free(d_lam);
+    dev_free(d_raw);
+    dev_free(d_prof);
+  };
+  if ((rc = dev_alloc(&d_lam, (size_t)n_padded)) || (rc = dev_alloc(&d_raw, (size_t)n_padded)) ||
+      (rc = dev_alloc(&d_prof, (size_t)n_out))) {
+    cleanup();
+    return rc;
+  }
+  hipError_t e = hipMemcpy(d_lam, lambdas, (size_t)n_padded * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_voigt_raw, dim3((unsigned)((n_padded + 255) / 256)), dim3(256), 0, 0, d_lam,
+                       n_padded, z, N, num_lines, d_raw);
+    hipLaunchKernelGGL(k_voigt_broaden, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, 0, d_raw,
+                       n_out, d_prof);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpy(profile_out, d_prof, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(GPDLA_ERR_HIP, "gpdla_voigt: %s", hipGetErrorString(e));
+  return GPDLA_OK;
+}
+
+int gpdla_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M, const double *d,
+                              int64_t n, int k, double *log_p, int device_id) {
+  if (!y || !mu || !M || !d || !log_p) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null pointer");
+  if (n < 1 || k < 1) return fail(GPDLA_ERR_INVALID_ARGUMENT, "n and k must be positive");
+  if (k > 256) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d too large", k);
+  int rc = select_device(device_id);
+  if (rc) return rc;
+  double *buf = nullptr;
+  int *d_status = nullptr;
+  const size_t nn = (size_t)n, ws = (size_t)k * (k + 1) / 2 + k + 2;
+  const size_t total = 3 * nn + nn * k + ws + 1;
+  if ((rc = dev_alloc(&buf, total))) return rc;
+  if ((rc = dev_alloc(&d_status, 1))) {
+    dev_free(buf);
+    return rc;
+  }
+  double *dy = buf, *dmu = dy + nn, *dd = dmu + nn, *dM = dd + nn, *dws = dM + nn * k, *dlp = dws + ws;
+  hipError_t e = hipMemcpy(dy, y, nn * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dmu, mu, nn * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dd, d, nn * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dM, M, nn * k * sizeof(double), hipMemcpyHostToDevice);
+  int status = 0;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_lowrank_single, dim3(1), dim3(256), 0, 0, dy, dmu, dM, dd, n, k, dws, dlp, d_status);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(log_p, dlp, sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost);
+  dev_free(buf);
+  dev_free(d_status);
+  if (e != hipSuccess) return fail(GPDLA_ERR_HIP, "gpdla_log_mvnpdf_low_rank: %s", hipGetErrorString(e));
+  if (status) {
+    *log_p = NAN;
+    return fail(GPDLA_ERR_NOT_POSITIVE_DEFINITE, "B = I + M' D^-1 M is not positive definite");
+  }
+  return GPDLA_OK;
+}
+
+int gpdla_process_batch_multi(const gpdla_model *, const gpdla_samples *, const gpdla_spectra *,
+                              const uint32_t *, const gpdla_config *, gpdla_results_multi *, int) {
+  return fail(GPDLA_ERR_UNSUPPORTED, "multi-DLA driver not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+/* gpdla.h -- C-ABI of the MI355X-native GP/DLA inference sweep (libgpdla.so).
+ *
+ * Drop-in boundary for ONE hot path of jibanCat/gp_dla_detection: the per-spectrum GP
+ * marginal-likelihood sweep.  The reference has no plugin registry; the path sits behind three
+ * plain call surfaces, and each entry point below replaces one of them (paths relative to the
+ * reference tree):
+ *
+ *   gpdla_voigt                  <-  voigt.c:253-304          MEX gateway  voigt(lambdas, z, N[, num_lines])
+ *   gpdla_log_mvnpdf_low_rank    <-  log_mvnpdf_low_rank.m:5  log_p = log_mvnpdf_low_rank(y, mu, M, d)
+ *   gpdla_process_batch          <-  process_qsos.m:88-233    the per-quasar loop + posteriors
+ *   gpdla_process_batch_multi    <-  multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-495
+ *
+ * plus a resident-data form (context + uploaded batch) so that a caller that keeps spectra in HBM
+ * -- the production case, and what bench.py times -- pays no PCIe inside the sweep.
+ *
+ * Conventions: plain pointers and sizes only, caller owns every buffer,
+ * no global state, all arithmetic IEEE fp64, MATLAB matrices are column-major, every function
+ * returns 0 or a negative gpdla_status.  All compute runs in hand-written HIP kernels for gfx950;
+ * there is NO CPU fallback: without a usable GPU every compute entry point returns
+ * GPDLA_ERR_NO_DEVICE.
+ */
+#ifndef GPDLA_H
+#define GPDLA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GPDLA_OK = 0,
+  GPDLA_ERR_INVALID_ARGUMENT = -1, /* null pointer, n_padded <= 6, num_lines outside [1,31], ... */
+  GPDLA_ERR_NO_DEVICE = -2,        /* no HIP device / device_id out of range */
+  GPDLA_ERR_HIP = -3,              /* a HIP runtime call failed; see gpdla_last_error() */
+  GPDLA_ERR_NOT_POSITIVE_DEFINITE = -4, /* chol(B) would throw, log_mvnpdf_low_rank.m:24 */
+  GPDLA_ERR_UNSUPPORTED = -5       /* e.g. k > GPDLA_MAX_K */
+} gpdla_status;
+
+#define GPDLA_MAX_K 40
+#define GPDLA_ABI_VERSION 1
+
+int gpdla_abi_version(void);
+/* Human-readable text of the most recent error on this thread (never NULL). */
+const char *gpdla_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stateless single-call surfaces (host pointers; device chosen by device_id).
+ * ------------------------------------------------------------------------------------------- */
+
+/* voigt.c:253-304.  profile_out has n_padded - 6 entries (numel(lambdas) - 2*width, :271).
+ * num_lines in [1, 31] (the MEX default when the 4th argument is omitted is 31, :16, :266).
+ * The reference validates nothing; here bad arguments return GPDLA_ERR_INVALID_ARGUMENT. */
+int gpdla_voigt(const double *lambdas, int64_t n_padded, double z, double N, int num_lines,
+                double *profile_out, int device_id);
+
+/* log_mvnpdf_low_rank.m:5-34.  y, mu, d: n;  M: n x k column-major (ld = n).  A non-PD
+ * B = I + M' D^-1 M returns GPDLA_ERR_NOT_POSITIVE_DEFINITE and *log_p = NaN (MATLAB: chol throws). */
+int gpdla_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M, const double *d,
+                              int64_t n, int k, double *log_p, int device_id);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batch surface: process_qsos.m.
+ * ------------------------------------------------------------------------------------------- */
+
+/* learned_qso_model_*.mat, process_qsos.m:30-35 (written by learn_qso_model.m:113-123). */
+typedef struct {
+  int32_t num_rest_pixels;          /* G = numel(rest_wavelengths) */
+  int32_t k;                        /* columns of M (set_parameters.m:36) */
+  const double *rest_wavelengths;   /* [G] ascending */
+  const double *mu;                 /* [G] */
+  const double *M;                  /* [G x k] column-major */
+  const double *log_omega;          /* [G] */
+  double log_c_0, log_tau_0, log_beta;
+} gpdla_model;
+
+/* dla_samples.mat, process_qsos.m:38-40 (+ lls_nhi_samples of set_lls_parameters.m:59-63 for the
+ * multi-DLA driver; may be NULL otherwise). */
+typedef struct {
+  int64_t num_dla_samples;          /* S (set_parameters.m:48) */
+  const double *offset_samples;     /* [S] in [0,1) */
+  const double *log_nhi_samples;    /* [S]  (only the multi-DLA MAP bookkeeping reads it) */
+  const double *nhi_samples;        /* [S] */
+  const double *lls_nhi_samples;    /* [S] or NULL */
+} gpdla_samples;
+
+/* preloaded_qsos.mat's ragged cell arrays (preload_qsos.m:64-79) flattened CSR-style, after the
+ * test_ind subset of process_qsos.m:56-61, plus the per-quasar scalars the loop reads. */
+typedef struct {
+  int64_t num_quasars;
+  const int64_t *offsets;           /* [num_quasars + 1] into the four pixel arrays */
+  const double *wavelengths;        /* observed, Angstrom */
+  const double *flux;
+  const double *noise_variance;
+  const uint8_t *pixel_mask;        /* nonzero = masked */
+  const double *z_qsos;             /* [num_quasars] */
+  const double *log_priors_no_dla;  /* [num_quasars]  process_qsos.m:130-131 (host logic) */
+  const double *log_priors_dla;     /* [num_quasars]  process_qsos.m:128-129; multi: [nq x max_dlas] col-major */
+  const double *log_priors_lls;     /* multi only (:208-210), else NULL */
+} gpdla_spectra;
+
+/* The set_parameters.m values the loop reads (process_qsos.m:104-105, 118, 159-176, 188). */
+typedef struct {
+  double min_lambda, max_lambda;    /* set_parameters.m:33-34 */
+  double lya_wavelength;            /* :5  */
+  double lyman_limit;               /* :7  */
+  double pixel_spacing;             /* :60 */
+  double max_z_cut, min_z_cut;      /* :65, :69 */
+  int32_t width;                    /* :59 -- must be 3 (voigt.c:229 hard-codes it) */
+  int32_t num_lines;                /* :63 */
+  /* multi-DLA only (process_qsos_multiple_dlas_meanflux.m:32-37, set_parameters_multi.m:75) */
+  int32_t max_dlas;
+  int32_t num_forest_lines;
+  double min_z_separation;
+  double prev_tau_0, prev_beta;
+} gpdla_config;
+
+/* Fills a gpdla_config with the reference's defaults (set_parameters.m / set_parameters_multi.m). */
+void gpdla_default_config(gpdla_config *cfg);
+
+/* Outputs of process_qsos.m:74-82, 224-233 (field names of :236-244).  Caller-owned; any pointer
+ * may be NULL to skip that field.  Entries of spectra that cannot be processed (no pixel survives
+ * the selection) are set to NaN, exactly as the reference's NaN pre-fill leaves them.
+ * sample_log_likelihoods_dla is [num_quasars][S] with the quasar index slowest (element
+ * (quasar_ind, i) of the MATLAB array at [quasar_ind * S + i]). */
+typedef struct {
+  double *min_z_dlas;                 /* [nq] */
+  double *max_z_dlas;                 /* [nq] */
+  double *log_likelihoods_no_dla;     /* [nq] */
+  double *sample_log_likelihoods_dla; /* [nq][S] */
+  double *log_likelihoods_dla;        /* [nq] */
+  double *log_posteriors_no_dla;      /* [nq] */
+  double *log_posteriors_dla;         /* [nq] */
+  double *model_posteriors;           /* [nq][2] = (no DLA, DLA) */
+  double *p_no_dlas;                  /* [nq] */
+  double *p_dlas;                     /* [nq] */
+  int32_t *status;                    /* [nq] 0 ok, 1 = empty spectrum (multi: all_exceptions, :232) */
+} gpdla_results;
+
+/* One-shot: host buffers in, host buffers out (uploads, sweeps, downloads). */
+int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
+                        const gpdla_spectra *spectra, const gpdla_config *config,
+                        gpdla_results *results, int device_id);
+
+/* ---------------------------------------------------------------------------------------------
+ * Resident form: a context owns a device, a stream, the replicated model + samples and scratch;
+ * a batch owns spectra in HBM.  Nothing here synchronises the device except where stated.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gpdla_context gpdla_context;
+typedef struct gpdla_batch gpdla_batch;
+
+int gpdla_context_create(int device_id, gpdla_context **ctx);
+void gpdla_context_destroy(gpdla_context *ctx);
+/* Use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) for all launches;
+ * NULL restores the context's own stream. */
+int gpdla_context_set_stream(gpdla_context *ctx, void *hip_stream);
+int gpdla_context_set_model(gpdla_context *ctx, const gpdla_model *model);      /* H2D copy */
+int gpdla_context_set_samples(gpdla_context *ctx, const gpdla_samples *samples);/* H2D copy */
+int gpdla_context_set_config(gpdla_context *ctx, const gpdla_config *config);
+int gpdla_context_synchronize(gpdla_context *ctx);
+
+/* Copies a CSR batch of spectra to HBM and allocates its result table there. */
+int gpdla_batch_upload(gpdla_context *ctx, const gpdla_spectra *spectra, gpdla_batch **batch);
+void gpdla_batch_destroy(gpdla_batch *batch);
+
+/* The hot path: selection + interpolation (process_qsos.m:102-146), null evidence (:149-151),
+ * S-sample Voigt/low-rank sweep (:185-199), evidence + posteriors (:203-213, :224-233) for every
+ * quasar of the batch.  Asynchronous on the context's stream; results stay in HBM. */
+int gpdla_batch_process(gpdla_context *ctx, gpdla_batch *batch);
+
+/* D2H copy of the batch's results (synchronises the stream). */
+int gpdla_batch_download(gpdla_context *ctx, gpdla_batch *batch, gpdla_results *results);
+
+/* Device pointer to the per-quasar summary table of the batch, [nq][GPDLA_SUMMARY_COLS] doubles:
+ * min_z_dla, max_z_dla, log_prior_no_dla, log_prior_dla, log_likelihood_no_dla, log_likelihood_dla,
+ * log_posterior_no_dla, log_posterior_dla, model_posterior[0], model_posterior[1], p_no_dla, p_dla.
+ * This is the row a multi-GPU run all-gathers. */
+#define GPDLA_SUMMARY_COLS 12
+int gpdla_batch_summary_device_ptr(gpdla_batch *batch, double **table, int64_t *num_quasars);
+/* Device pointer to sample_log_likelihoods_dla [nq][S] of the batch. */
+int gpdla_batch_samples_device_ptr(gpdla_batch *batch, double **table, int64_t *num_quasars,
+                                   int64_t *num_samples);
+
+/* Profiling aid for bench.py: duration in ms of the most recent sweep-kernel launch of this
+ * context, measured with hipEvents on the launch stream (synchronises).  Negative if none. */
+double gpdla_context_last_sweep_ms(gpdla_context *ctx);
+/* Enables/disables the hipEvent bracketing above (off by default: zero overhead). */
+int gpdla_context_set_timing(gpdla_context *ctx, int enabled);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-DLA driver: multi_dlas/process_qsos_multiple_dlas_meanflux.m.
+ * base_sample_inds: [nq][max_dlas-1][S] uint32, 1-BASED as in the reference's output file (:116,
+ * :476); it is an INPUT here because MATLAB's rng('default') + randsample stream (:143, :471-472)
+ * cannot be reproduced outside MATLAB.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  double *min_z_dlas, *max_z_dlas;        /* [nq] */
+  double *log_likelihoods_no_dla;         /* [nq] */
+  double *sample_log_likelihoods_dla;     /* [nq][max_dlas][S] */
+  double *sample_log_likelihoods_lls;     /* [nq][S] */
+  double *log_likelihoods_dla;            /* [nq][max_dlas] */
+  double *log_likelihoods_lls;            /* [nq] */
+  double *log_posteriors_no_dla;          /* [nq] */
+  double *log_posteriors_lls;             /* [nq] */
+  double *log_posteriors_dla;             /* [nq][max_dlas] */
+  double *model_posteriors;               /* [nq][2 + max_dlas] = (no DLA, LLS, 1..max_dlas DLAs) */
+  double *p_no_dlas, *p_lls, *p_dlas;     /* [nq] */
+  double *MAP_z_dlas, *MAP_log_nhis, *MAP_inds; /* [nq][max_dlas(model)][max_dlas(slot)], NaN unused */
+  int32_t *status;                        /* [nq] 1 = all_exceptions (:232) */
+} gpdla_results_multi;
+
+int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
+                              const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
+                              const gpdla_config *config, gpdla_results_multi *results,
+                              int device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

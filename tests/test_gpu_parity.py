@@ -1,0 +1,254 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the golden fixtures.
+
+Tolerance (BASELINE.json north_star): fp64, |delta| <= 1e-8 absolute on every log-likelihood /
+log-evidence; absorption profiles <= 2e-13 absolute (the reference's own scipy-vs-mpmath spread).
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+import gp_dla_detection_amd as gp
+from gp_dla_detection_amd import _lib, synthetic
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def model20():
+    return synthetic.make_model(20)
+
+
+def flat_priors(n):
+    return np.full(n, np.log(0.9)), np.full(n, np.log(0.1))
+
+
+# ---------------------------------------------------------------- voigt (voigt.c:253-304)
+
+def test_voigt_golden_profiles(golden):
+    g = golden("voigt_profiles.npz")
+    for c in range(int(g["num_cases"])):
+        z, N, nl = g[f"args_{c}"]
+        prof = gp.voigt(g[f"lambdas_{c}"], z, N, int(nl))
+        assert prof.shape == (g[f"lambdas_{c}"].size - 6,)
+        assert np.abs(prof - g[f"profile_{c}"]).max() < 2e-13, c
+
+
+def test_voigt_matches_oracle_on_irregular_grids(oracle):
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        n = int(rng.integers(7, 900))
+        lam = np.sort(rng.uniform(3600.0, 9000.0, n))  # not log-uniform, arbitrary length
+        z = float(rng.uniform(2.0, 5.0))
+        N = 10.0 ** float(rng.uniform(17.0, 23.0))
+        nl = int(rng.choice([1, 2, 3, 7, 31]))
+        got = gp.voigt(lam, z, N, nl)
+        want = oracle.voigt(lam, z, N, nl)
+        assert np.abs(got - want).max() < 2e-13, (trial, n, nl)
+
+
+def test_voigt_default_num_lines_is_31(oracle):
+    lam = 10.0 ** (3.6 + 1e-4 * np.arange(300))
+    np.testing.assert_allclose(gp.voigt(lam, 2.4, 1e21), oracle.voigt(lam, 2.4, 1e21, 31),
+                               rtol=0, atol=2e-13)
+
+
+def test_voigt_bad_arguments():
+    with pytest.raises(_lib.GpdlaError):
+        gp.voigt(np.linspace(4000, 4001, 6), 2.0, 1e20, 3)
+    with pytest.raises(_lib.GpdlaError):
+        gp.voigt(np.linspace(4000, 4100, 60), 2.0, 1e20, 0)
+    with pytest.raises(_lib.GpdlaError):
+        gp.voigt(np.linspace(4000, 4100, 60), 2.0, 1e20, 32)
+
+
+# ------------------------------------------------ log_mvnpdf_low_rank (log_mvnpdf_low_rank.m)
+
+def test_log_mvnpdf_golden(golden):
+    g = golden("log_mvnpdf_low_rank.npz")
+    for c in range(int(g["num_cases"])):
+        lp = gp.log_mvnpdf_low_rank(g[f"y_{c}"], g[f"mu_{c}"], g[f"M_{c}"], g[f"d_{c}"])
+        assert abs(lp - float(g[f"log_p_{c}"])) < TOL, c
+
+
+def test_log_mvnpdf_not_positive_definite():
+    n, k = 6, 2
+    with pytest.raises(_lib.GpdlaError) as e:
+        gp.log_mvnpdf_low_rank(np.zeros(n), np.zeros(n), np.ones((n, k)), np.full(n, -0.5))
+    assert e.value.code == -4
+
+
+# ---------------------------------------------------------- process_qsos (process_qsos.m)
+
+def run_gpu(model, samples, spectra):
+    lp = flat_priors(len(spectra))
+    return gp.process_qsos(model, samples, spectra, log_priors=lp)
+
+
+def run_oracle(oracle, model, samples, sp):
+    return oracle.process_spectrum(model, samples["offset_samples"], samples["nhi_samples"],
+                                   sp["wavelengths"], sp["flux"], sp["noise_variance"],
+                                   sp["pixel_mask"], sp["z_qso"], num_threads=0)
+
+
+def test_config1_golden_spectrum(golden, model20):
+    """BASELINE config 1: n = 800, k = 20, S = 1000, 5 % masked (NaN flux / inf variance there)."""
+    g = golden("spectrum_config1.npz")
+    samples = synthetic.make_samples(1000)
+    sp = dict(wavelengths=g["wavelengths"], flux=g["flux"], noise_variance=g["noise_variance"],
+              pixel_mask=g["pixel_mask"], z_qso=float(g["z_qso"]))
+    out = run_gpu(model20, samples, [sp])
+    assert out["status"][0] == 0
+    assert abs(out["min_z_dlas"][0] - float(g["min_z_dla"])) < 1e-14
+    assert abs(out["max_z_dlas"][0] - float(g["max_z_dla"])) < 1e-14
+    assert abs(out["log_likelihoods_no_dla"][0] - float(g["log_likelihood_no_dla"])) < TOL
+    d = np.abs(out["sample_log_likelihoods_dla"][0] - g["sample_log_likelihoods_dla"])
+    assert d.max() < TOL, (d.max(), int(d.argmax()))
+    assert abs(out["log_likelihoods_dla"][0] - float(g["log_likelihood_dla"])) < TOL
+
+
+def test_ragged_batch_vs_oracle(oracle, model20):
+    """Several quasars of different lengths, with and without masks, one launch."""
+    samples = synthetic.make_samples(200)
+    sizes = [203, 400, 777, 1001, 64, 1250]
+    spectra = [synthetic.make_spectrum(10 + i, n, model20, mask_fraction=0.05 if i % 2 else 0.0)
+               for i, n in enumerate(sizes)]
+    out = run_gpu(model20, samples, spectra)
+    lp_no, lp_dla = flat_priors(len(spectra))
+    for i, sp in enumerate(spectra):
+        ref = run_oracle(oracle, model20, samples, sp)
+        assert out["status"][i] == 0
+        assert abs(out["log_likelihoods_no_dla"][i] - ref["log_likelihood_no_dla"]) < TOL, i
+        d = np.abs(out["sample_log_likelihoods_dla"][i] - ref["sample_log_likelihoods_dla"])
+        assert d.max() < TOL, (i, d.max())
+        assert abs(out["log_likelihoods_dla"][i] - ref["log_likelihood_dla"]) < TOL, i
+        # process_qsos.m:153-154, 212-213, 224-233
+        post = np.array([lp_no[i] + ref["log_likelihood_no_dla"], lp_dla[i] + ref["log_likelihood_dla"]])
+        assert abs(out["log_posteriors_no_dla"][i] - post[0]) < TOL
+        assert abs(out["log_posteriors_dla"][i] - post[1]) < TOL
+        mp = np.exp(post - post.max())
+        mp /= mp.sum()
+        np.testing.assert_allclose(out["model_posteriors"][i], mp, rtol=0, atol=1e-9)
+        assert abs(out["p_no_dlas"][i] - mp[0]) < 1e-9 and abs(out["p_dlas"][i] - (1 - mp[0])) < 1e-9
+
+
+def test_empty_and_fully_masked_spectra_stay_nan(oracle, model20):
+    samples = synthetic.make_samples(48)
+    good = synthetic.make_spectrum(30, 300, model20)
+    red = dict(wavelengths=np.linspace(9000, 9100, 50), flux=np.ones(50),
+               noise_variance=np.ones(50), pixel_mask=np.zeros(50, np.uint8), z_qso=2.5)
+    masked = synthetic.make_spectrum(31, 250, model20)
+    masked["pixel_mask"] = np.ones_like(masked["pixel_mask"])
+    out = run_gpu(model20, samples, [red, good, masked])
+    assert list(out["status"]) == [1, 0, 1]
+    for i in (0, 2):  # the reference leaves its NaN pre-fill in place (process_qsos.m:74-82)
+        assert np.isnan(out["sample_log_likelihoods_dla"][i]).all()
+        assert np.isnan(out["log_likelihoods_no_dla"][i]) and np.isnan(out["log_likelihoods_dla"][i])
+        assert np.isnan(out["model_posteriors"][i]).all()
+    ref = run_oracle(oracle, model20, samples, good)
+    assert np.abs(out["sample_log_likelihoods_dla"][1] - ref["sample_log_likelihoods_dla"]).max() < TOL
+
+
+def test_unsorted_wavelengths(oracle, model20):
+    """The reference never assumes ascending wavelengths; neither may the selection scan."""
+    samples = synthetic.make_samples(32)
+    sp = synthetic.make_spectrum(40, 300, model20, mask_fraction=0.05)
+    order = np.random.default_rng(1).permutation(sp["wavelengths"].size)
+    for key in ("wavelengths", "flux", "noise_variance", "pixel_mask"):
+        sp[key] = sp[key][order]
+    ref = run_oracle(oracle, model20, samples, sp)
+    out = run_gpu(model20, samples, [sp])
+    assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL
+
+
+def test_num_lines_31_and_1(oracle, model20):
+    samples = synthetic.make_samples(40)
+    sp = synthetic.make_spectrum(41, 350, model20)
+    for nl in (1, 31):
+        p = gp.Parameters(num_lines=nl)
+        out = gp.process_qsos(model20, samples, [sp], log_priors=flat_priors(1), params=p)
+        from oracle.oracle import OracleParams
+        ref = oracle.process_spectrum(model20, samples["offset_samples"], samples["nhi_samples"],
+                                      sp["wavelengths"], sp["flux"], sp["noise_variance"],
+                                      sp["pixel_mask"], sp["z_qso"], params=OracleParams(num_lines=nl))
+        assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL, nl
+
+
+def test_rank_40_model(oracle):
+    """BASELINE config 5's shape (k = 40) in fp64: the tile-split sweep."""
+    model = synthetic.make_model(40)
+    samples = synthetic.make_samples(50)
+    sp = synthetic.make_spectrum(50, 420, model, mask_fraction=0.05)
+    out = run_gpu(model, samples, [sp])
+    ref = run_oracle(oracle, model, samples, sp)
+    assert abs(out["log_likelihoods_no_dla"][0] - ref["log_likelihood_no_dla"]) < TOL
+    assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL
+
+
+def test_small_rank_model(oracle):
+    model = synthetic.make_model(5)
+    samples = synthetic.make_samples(20)
+    sp = synthetic.make_spectrum(51, 210, model)
+    out = run_gpu(model, samples, [sp])
+    ref = run_oracle(oracle, model, samples, sp)
+    assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL
+
+
+# -------------------------------------------------- BASELINE config 2 sizes, by properties
+
+def test_full_size_properties(oracle, model20):
+    """n = 1500, S = 10000 (BASELINE config 2's per-quasar shape) on 3 quasars: the oracle checks a
+    random subset of samples; size-independent properties cover the rest."""
+    S = 10000
+    samples = synthetic.make_samples(S)
+    spectra = synthetic.make_spectra(3, 1500, model20, first_index=100)
+    out = run_gpu(model20, samples, spectra)
+    sll = out["sample_log_likelihoods_dla"]
+    assert sll.shape == (3, S) and np.isfinite(sll).all()
+    # (a) evidence is the log-mean-exp of the sample table (process_qsos.m:203-210)
+    mx = sll.max(axis=1)
+    ev = mx + np.log(np.mean(np.exp(sll - mx[:, None]), axis=1))
+    np.testing.assert_allclose(out["log_likelihoods_dla"], ev, rtol=0, atol=TOL)
+    # (b) oracle on a random subset of the samples (the oracle takes any sample list)
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(S, 48, replace=False))
+    sub = dict(offset_samples=samples["offset_samples"][pick], nhi_samples=samples["nhi_samples"][pick])
+    for i, sp in enumerate(spectra):
+        ref = run_oracle(oracle, model20, sub, sp)
+        assert abs(out["log_likelihoods_no_dla"][i] - ref["log_likelihood_no_dla"]) < TOL
+        d = np.abs(sll[i, pick] - ref["sample_log_likelihoods_dla"])
+        assert d.max() < TOL, (i, d.max())
+    # (c) the result of a sample does not depend on which other samples share its launch:
+    #     permute the sample list and compare entry by entry (bit-exact)
+    perm = rng.permutation(S)
+    shuffled = {k: v[perm] for k, v in samples.items()}
+    out2 = run_gpu(model20, shuffled, spectra[:1])
+    np.testing.assert_array_equal(out2["sample_log_likelihoods_dla"][0], sll[0, perm])
+    # (d) a quasar with an injected DLA prefers the DLA model and recovers its redshift
+    for i, sp in enumerate(spectra):
+        if sp["true_z_dla"] is not None and sp["true_log_nhi"] > 20.5:
+            zs = out["min_z_dlas"][i] + (out["max_z_dlas"][i] - out["min_z_dlas"][i]) * samples["offset_samples"]
+            assert abs(zs[sll[i].argmax()] - sp["true_z_dla"]) < 5e-3
+            assert out["log_likelihoods_dla"][i] > out["log_likelihoods_no_dla"][i]
+
+
+def test_resident_batch_is_idempotent(model20):
+    """Processing the same resident batch twice gives bit-identical tables (no stale state)."""
+    samples = synthetic.make_samples(500)
+    spectra = synthetic.make_spectra(4, 600, model20, first_index=200)
+    ctx = gp.Context(0)
+    ctx.set_model(model20)
+    ctx.set_samples(samples)
+    batch = ctx.upload(spectra, *flat_priors(4))
+    batch.process()
+    a = batch.download()
+    batch.process()
+    b = batch.download()
+    for key in ("sample_log_likelihoods_dla", "log_likelihoods_dla", "model_posteriors"):
+        np.testing.assert_array_equal(a[key], b[key])
+    t = batch.summary_tensor()
+    assert tuple(t.shape) == (4, 12) and t.is_cuda
+    np.testing.assert_array_equal(t.cpu().numpy()[:, 5], a["log_likelihoods_dla"])
+    batch.close()
+    ctx.close()
