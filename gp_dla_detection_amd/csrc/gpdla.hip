@@ -134,7 +134,7 @@ struct gpdla_batch {
   double *d_lp_no = nullptr, *d_lp_dla = nullptr;
   QuasarMeta *d_meta = nullptr;
   PixelRow *d_pix = nullptr;
-  double *d_Mi = nullptr, *d_lam = nullptr, *d_pm = nullptr;
+  double *d_Mi = nullptr, *d_lam = nullptr, *d_records = nullptr;
   double *d_sample_ll = nullptr, *d_ll_no = nullptr, *d_summary = nullptr;
   int64_t pool_rows = 0;
   int32_t k = 0, tiles_w = 0, ntiles = 0;
@@ -329,7 +329,7 @@ void gpdla_batch_destroy(gpdla_batch *b) {
   dev_free(b->d_pix);
   dev_free(b->d_Mi);
   dev_free(b->d_lam);
-  dev_free(b->d_pm);
+  dev_free(b->d_records);
   dev_free(b->d_sample_ll);
   dev_free(b->d_ll_no);
   dev_free(b->d_summary);
@@ -387,7 +387,7 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   chk(dev_alloc(&b->d_pix, (size_t)rows));
   chk(dev_alloc(&b->d_Mi, (size_t)rows * b->k));
   chk(dev_alloc(&b->d_lam, (size_t)lam));
-  chk(dev_alloc(&b->d_pm, (size_t)(rows / 4) * b->ntiles * 64));
+  chk(dev_alloc(&b->d_records, (size_t)(rows / 4) * (b->ntiles * 64 + 32)));
   chk(dev_alloc(&b->d_sample_ll, (size_t)nq * b->S));
   chk(dev_alloc(&b->d_ll_no, (size_t)nq));
   chk(dev_alloc(&b->d_summary, (size_t)nq * GPDLA_SUMMARY_COLS));
@@ -408,22 +408,24 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
 
 namespace {
 
-template <int NTW, int TS>
-int launch_sweep(gpdla_context *c, gpdla_batch *b, const SweepArgs &args) {
-  constexpr int groups = kWavesPerBlock / TS;
+template <int NTW, int TS, int CH>
+int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
+  constexpr int groups = kSweepWaves / TS;
   const int L = args.num_lines;
-  const size_t loop_doubles = (size_t)kChunkSteps * b->ntiles * 64 +
-                              (size_t)kWavesPerBlock * kSamplesPerWave * kRingStride +
-                              (size_t)groups * kSamplesPerWave * L;
-  const size_t epi_doubles = (size_t)groups * b->ntiles * 16 * (kSamplesPerWave + 1);
-  const size_t lds = std::max(loop_doubles, epi_doubles) * sizeof(double);
+  const size_t RD = (size_t)b->ntiles * 64 + 32;
+  const size_t stage_doubles = 2 * (size_t)CH * RD;
+  const size_t epi_doubles = (size_t)groups * 4 * b->ntiles * 16;
+  if (epi_doubles > stage_doubles) return fail(GPDLA_ERR_UNSUPPORTED, "epilogue does not fit the stage buffers");
+  const size_t lds = (stage_doubles + (size_t)kSweepWaves * kSamplesPerWave * kRingStride +
+                      (size_t)groups * kSamplesPerWave * L) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "sweep needs %zu B of LDS", lds);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<NTW, TS>),
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<NTW, TS, CH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.blocks_per_quasar = (int32_t)((b->S + 1 + groups * kSamplesPerWave - 1) / (groups * kSamplesPerWave));
   const int64_t nblocks = 8 * ((b->nq + 7) / 8) * (int64_t)args.blocks_per_quasar;
   if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "batch too large for one launch");
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  hipLaunchKernelGGL((k_sweep<NTW, TS>), dim3((unsigned)nblocks), dim3(256), lds, c->stream, args);
+  hipLaunchKernelGGL((k_sweep<NTW, TS, CH>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
   HIP_TRY(hipGetLastError());
   if (c->timing) {
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -469,15 +471,17 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   hipLaunchKernelGGL(k_prepare, dim3((unsigned)b->nq), dim3(256), 0, st, pa);
   HIP_TRY(hipGetLastError());
 
-  BuildPmArgs ba;
+  BuildRecordsArgs ba;
   ba.meta = b->d_meta;
+  ba.pix = b->d_pix;
   ba.Mi = b->d_Mi;
-  ba.pm = b->d_pm;
+  ba.lam_pad = b->d_lam;
+  ba.records = b->d_records;
   ba.k = b->k;
   ba.tiles_w = b->tiles_w;
   ba.ntiles = b->ntiles;
   ba.blocks_per_quasar = 16;
-  hipLaunchKernelGGL(k_build_pm, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
+  hipLaunchKernelGGL(k_build_records, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
   HIP_TRY(hipGetLastError());
 
   // NaN pre-fill, as process_qsos.m:74-82 does for quasars that are skipped
@@ -486,9 +490,8 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
 
   SweepArgs sa;
   sa.meta = b->d_meta;
-  sa.pix = b->d_pix;
+  sa.records = b->d_records;
   sa.lam_pad = b->d_lam;
-  sa.pm = b->d_pm;
   sa.offset_samples = c->d_offset;
   sa.nhi_samples = c->d_nhi;
   sa.perm = c->d_perm;
@@ -501,12 +504,11 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.sample_ll = b->d_sample_ll;
   sa.ll_no_dla = b->d_ll_no;
   int rc;
+  sa.blocks_per_quasar = 0;  // set by launch_sweep
   if (b->ntiles <= 16) {
-    sa.blocks_per_quasar = (int32_t)((b->S + 1 + 63) / 64);
-    rc = launch_sweep<16, 1>(c, b, sa);
+    rc = launch_sweep<16, 1, 4>(c, b, sa);
   } else if (b->ntiles <= 56) {
-    sa.blocks_per_quasar = (int32_t)((b->S + 1 + 15) / 16);
-    rc = launch_sweep<14, 4>(c, b, sa);
+    rc = launch_sweep<14, 4, 1>(c, b, sa);
   } else {
     rc = fail(GPDLA_ERR_UNSUPPORTED, "k = %d needs %d B tiles (max 56)", b->k, b->ntiles);
   }

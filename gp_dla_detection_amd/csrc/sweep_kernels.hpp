@@ -3,8 +3,8 @@
 // Kernels (reference lines they replace; paths relative to the reference tree):
 //   k_prepare   process_qsos.m:102-119, 138-146, 159-176   per-quasar pixel selection, GP
 //                                                          interpolation, noise scaling, padding
-//   k_build_pm  (no reference counterpart)                  packs vech(m m') | m per pixel into
-//                                                          MFMA B-operand tiles
+//   k_build_records (no reference counterpart)              packs vech(m m') | m per pixel into MFMA
+//                                                          B-operand tiles + the per-pixel vectors
 //   k_sweep     process_qsos.m:149-151 and 185-199          fused Voigt profile -> scaled
 //               + voigt.c:278-299 + log_mvnpdf_low_rank.m   low-rank Gaussian log-pdf, one
 //                                                          sample per MFMA row
@@ -32,7 +32,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxLines = 31;
 constexpr int kWavesPerBlock = 4;
 constexpr int kSamplesPerWave = 16;   // rows of the 16x16x4 MFMA
-constexpr int kChunkSteps = 4;        // K-steps of B tiles staged in LDS at a time
 constexpr int kRingStride = 17;       // doubles per sample row of the raw-profile ring (16 + pad)
 constexpr double kLog2Pi = 1.83787706640934534;  // log_mvnpdf_low_rank.m:7
 
@@ -230,72 +229,104 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_build_pm: B-operand tiles.  PM[q][step][tile][64]: lane l = 16*jj + col holds, for pixel
-// 4*step + jj, column 16*tile + col of [vech(m m') | m]  (row-wise lower triangle:
-// idx(i, j) = i(i+1)/2 + j, j <= i).  tiles_w = ceil(k(k+1)/2 / 16) tiles take the weight w,
-// the following tiles_u = ceil(k/16) take u.
+// k_build_records: everything one K-step of the sweep reads, packed contiguously so that a
+// chunk of steps is ONE linear global->LDS DMA (global_load_lds_dwordx4).
+//
+// record(q, t) = RD doubles, RD = ntiles*64 + 32:
+//   [0, ntiles*64)   B-operand tiles.  Tile c, lane l = 16*jj + col holds, for pixel 4t + jj,
+//                    column 16c + col of [vech(m m') | m]  (row-wise lower triangle:
+//                    idx(i, j) = i(i+1)/2 + j, j <= i).  The first tiles_w = ceil(k(k+1)/2 / 16)
+//                    tiles take the weight w, the following ceil(k/16) tiles take u.
+//   [+0, +16)        PixelRow (y, mu, omega2, nu) of pixels 4t .. 4t+3
+//   [+16, +20)       padded wavelengths 4(t+2) .. 4(t+2)+3 (the raw profile runs two steps ahead)
+//   [+20, +32)       unused (keeps records 16-byte granular and 256-byte aligned)
 // ------------------------------------------------------------------------------------------
-struct BuildPmArgs {
+struct BuildRecordsArgs {
   const QuasarMeta *meta;
+  const PixelRow *pix;
   const double *Mi;
-  double *pm;             // pool, [pix_off/4 + step][ntiles][64]
+  const double *lam_pad;
+  double *records;        // pool, record index = pix_off/4 + step
   int32_t k, tiles_w, ntiles;
   int32_t blocks_per_quasar;
 };
 
-__global__ __launch_bounds__(256) void k_build_pm(BuildPmArgs a) {
+__device__ __forceinline__ int record_doubles(int ntiles) { return ntiles * 64 + 32; }
+
+__global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
   const int q = blockIdx.x / a.blocks_per_quasar;
   const int bq = blockIdx.x % a.blocks_per_quasar;
   const QuasarMeta m = a.meta[q];
-  const int64_t per_step = (int64_t)a.ntiles * 64;
-  const int64_t total = (int64_t)m.steps * per_step;
+  const int RD = record_doubles(a.ntiles);
+  const int64_t total = (int64_t)m.steps * RD;
   const int ncol_w = a.k * (a.k + 1) / 2;
+  const int n_pad = m.n_u + 6;
+  double *out = a.records + (m.pix_off / 4) * (int64_t)RD;
   for (int64_t e = (int64_t)bq * 256 + threadIdx.x; e < total;
        e += (int64_t)a.blocks_per_quasar * 256) {
-    const int step = (int)(e / per_step);
-    const int rem = (int)(e - (int64_t)step * per_step);
-    const int tile = rem >> 6, l = rem & 63;
-    const int jj = l >> 4, col = l & 15;
-    const double *row = a.Mi + (m.pix_off + 4 * (int64_t)step + jj) * a.k;
+    const int step = (int)(e / RD);
+    const int rem = (int)(e - (int64_t)step * RD);
     double v = 0.0;
-    if (tile < a.tiles_w) {
-      const int c = tile * 16 + col;
-      if (c < ncol_w) {
-        int i = (int)((sqrt(8.0 * c + 1.0) - 1.0) * 0.5);
-        while ((i + 1) * (i + 2) / 2 <= c) ++i;
-        while (i * (i + 1) / 2 > c) --i;
-        const int j = c - i * (i + 1) / 2;
-        v = row[i] * row[j];
+    if (rem < a.ntiles * 64) {
+      const int tile = rem >> 6, l = rem & 63;
+      const int jj = l >> 4, col = l & 15;
+      const double *row = a.Mi + (m.pix_off + 4 * (int64_t)step + jj) * a.k;
+      if (tile < a.tiles_w) {
+        const int c = tile * 16 + col;
+        if (c < ncol_w) {
+          int i = (int)((sqrt(8.0 * c + 1.0) - 1.0) * 0.5);
+          while ((i + 1) * (i + 2) / 2 <= c) ++i;
+          while (i * (i + 1) / 2 > c) --i;
+          const int j = c - i * (i + 1) / 2;
+          v = row[i] * row[j];
+        }
+      } else {
+        const int c = (tile - a.tiles_w) * 16 + col;
+        if (c < a.k) v = row[c];
       }
     } else {
-      const int c = (tile - a.tiles_w) * 16 + col;
-      if (c < a.k) v = row[c];
+      const int r2 = rem - a.ntiles * 64;
+      if (r2 < 16) {
+        const PixelRow px = a.pix[m.pix_off + 4 * (int64_t)step + (r2 >> 2)];
+        const int f = r2 & 3;
+        v = f == 0 ? px.y : f == 1 ? px.mu : f == 2 ? px.omega2 : px.nu;
+      } else if (r2 < 20) {
+        int P = 4 * (step + 2) + (r2 - 16);
+        if (P > n_pad - 1) P = n_pad - 1;
+        v = a.lam_pad[m.lam_off + P];
+      }
     }
-    a.pm[(m.pix_off / 4) * per_step + e] = v;
+    out[e] = v;
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_sweep.
 //
-// Grid: 8 * ceil(nq/8) * blocks_per_quasar blocks of 256 threads = 4 waves, flattened in x.
-// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the XCD group), so block i
-// works on quasar 8*(i/8/bpq) + i%8: every XCD streams ONE quasar's 3 MB of B tiles at a time
-// and keeps them in its own 4 MB L2.  A wave owns 16 sample slots
-// (MFMA rows); lane l = 16*jj + s works on sample slot s and, at K-step t, on pixel 4t + jj.
-// Slot S (one past the last sample) is the null model (a = 1): process_qsos.m:149-151.
-// Samples are visited in ascending z_DLA order (perm), so the lanes of a wave sit within a few
-// pixels of each other relative to every line centre and the accurate-Faddeeva branch is taken
-// by whole waves.
+// Grid: 8 * ceil(nq/8) * blocks_per_quasar blocks of 512 threads = 8 waves (two per SIMD, so one
+// wave's Voigt VALU work overlaps the other's MFMAs), flattened in x.  Workgroups are dealt
+// round-robin over the 8 XCDs, so block i works on quasar 8*(i/8/bpq) + i%8: every XCD streams ONE
+// quasar's records at a time and keeps them in its own 4 MB L2.
+//
+// A wave owns 16 sample slots (MFMA rows); lane l = 16*jj + s works on sample slot s and, at
+// K-step t, on pixel 4t + jj.  Slot S (one past the last sample) is the null model (a = 1):
+// process_qsos.m:149-151.  Samples are visited in ascending z_DLA order (perm), so the lanes of a
+// wave sit within a few pixels of each other relative to every line centre and the accurate
+// Faddeeva branch is taken by whole waves, one line at a time.
 //
 // TS ("tile split"): number of waves that share one group of 16 samples and split the B tiles
 // between them (1 for k <= 20; 4 for k <= 40, where 55 tiles of accumulators do not fit one wave).
+//
+// LDS (one dynamic array): two chunk buffers of kChunkSteps records (global_load_lds double
+// buffering) | raw-profile rings | per-sample line multipliers.  After the loop the chunk buffers
+// are reused by the Cholesky epilogue.
 // ------------------------------------------------------------------------------------------
+constexpr int kSweepWaves = 8;
+
 struct SweepArgs {
   const QuasarMeta *meta;
-  const PixelRow *pix;
+  const double *records;
   const double *lam_pad;
-  const double *pm;
   const double *offset_samples;   // [S]
   const double *nhi_samples;      // [S]
   const int32_t *perm;            // [S] sample indices in ascending offset (= z_DLA) order
@@ -307,10 +338,61 @@ struct SweepArgs {
   double *ll_no_dla;              // [nq]      process_qsos.m:149
 };
 
-template <int NTW, int TS>
-__global__ __launch_bounds__(256) void k_sweep(SweepArgs a) {
+// 1/a to ~1 ulp: v_rcp_f64 seed + two Newton steps (a is never 0/inf/denormal here).
+__device__ __forceinline__ double fast_rcp(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  double e = fma(-a, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-a, r, 1.0);
+  return fma(r, e, r);
+}
+
+// exp(x) for x <= 0 (optical depths): x = n ln2 + r, |r| <= ln2/2, degree-12 Taylor, ldexp.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = fmax(x, -800.0);  // exp(-800) = 0 in fp64; keeps n in int range
+  const double n = rint(x * 1.4426950408889634);
+  double r = fma(-n, 0.6931471803691238, x);      // ln2 high part (trailing bits zero)
+  r = fma(-n, 1.9082149292705877e-10, r);         // ln2 low part
+  double p = 2.08767569878681e-09;                // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);           // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);
+  p = fma(p, r, 2.755731922398589e-06);
+  p = fma(p, r, 2.48015873015873e-05);
+  p = fma(p, r, 0.0001984126984126984);
+  p = fma(p, r, 0.001388888888888889);
+  p = fma(p, r, 0.008333333333333333);
+  p = fma(p, r, 0.041666666666666664);
+  p = fma(p, r, 0.16666666666666666);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
+// Re w(x+iy) sqrt(pi)/y for |x| >= 30 given x2 = x^2 (see faddeeva.hpp rew_wing), with the fast
+// reciprocal.  Returns the value with the y/sqrt(pi) factor left out.
+__device__ __forceinline__ double wing_core(double x2, double y2) {
+  const double rho = fast_rcp(x2 + y2);
+  double t = fma(kT6, rho, kT5);
+  t = fma(t, rho, kT4);
+  t = fma(t, rho, kT3);
+  t = fma(t, rho, kT2);
+  t = fma(t, rho, kT1);
+  t = fma(t, rho, kT0);
+  t = fma(-2.0 * y2 * rho, rho, t);
+  return rho * t;
+}
+
+__device__ __forceinline__ void glds16(const double *gsrc, double *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void *)gsrc,
+      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int NTW, int TS, int kChunkSteps>
+__global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   extern __shared__ double smem[];
-  constexpr int GROUPS = kWavesPerBlock / TS;          // sample groups per block
+  constexpr int GROUPS = kSweepWaves / TS;  // sample groups per block
   const int64_t xj = blockIdx.x >> 3;
   const int64_t q = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
   const int bq = (int)(xj % a.blocks_per_quasar);
@@ -322,12 +404,11 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a) {
   const int s = lane & 15, jj = lane >> 4;
   const int L = a.num_lines;
   const int ntiles = a.ntiles;
+  const int RD = ntiles * 64 + 32;
 
-  // LDS carve-up.  During the loop: B-tile chunk | raw-profile rings | per-sample multipliers.
-  // After the loop the whole region is reused for the Cholesky epilogue.
-  double *pm_s = smem;                                                  // [kChunkSteps][ntiles][64]
-  double *ring = pm_s + (size_t)kChunkSteps * ntiles * 64;             // [4 waves][16][17]
-  double *mult_s = ring + kWavesPerBlock * kSamplesPerWave * kRingStride;  // [GROUPS*16][L]
+  double *stage = smem;                                            // [2][kChunkSteps][RD]
+  double *ring = stage + (size_t)2 * kChunkSteps * RD;             // [8 waves][16][17]
+  double *mult_s = ring + kSweepWaves * kSamplesPerWave * kRingStride;  // [GROUPS*16][L]
 
   const int64_t slot = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave + s;
   const bool is_sample = slot < a.S;
@@ -343,145 +424,184 @@ __global__ __launch_bounds__(256) void k_sweep(SweepArgs a) {
   }
   double *my_ring = ring + (size_t)(wave * kSamplesPerWave + s) * kRingStride;
   const double *lam = a.lam_pad + m.lam_off;
-  const PixelRow *pix = a.pix + m.pix_off;
   const int n_pad = m.n_u + 6;
-  const double nscale = nhi * g_lines.inv_sqrt2pi_sigma;
-  __syncthreads();
+  // exp(N * total / (sqrt(2 pi) sigma)) with total = -Sum lead_j Re w_j (voigt.c:288-291)
+  const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
+  const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
+  const int nchunks = (m.steps + kChunkSteps - 1) / kChunkSteps;
 
-  // raw (un-broadened) profile at padded pixel P: voigt.c:282-292
-  auto raw_at = [&](int P) -> double {
-    const double lamP = lam[P < n_pad ? P : n_pad - 1];
+  // asynchronous global -> LDS copy of one chunk of records (1 KiB per wave-instruction)
+  auto issue_chunk = [&](int c) {
+    const int csteps = min(kChunkSteps, m.steps - c * kChunkSteps);
+    const int units = csteps * (RD / 2);  // 16-byte units
+    const double *src = rec_base + (size_t)c * kChunkSteps * RD;
+    double *dst = stage + (size_t)(c & 1) * kChunkSteps * RD;
+    for (int i = wave; i * 64 < units; i += kSweepWaves) {
+      const int unit = i * 64 + lane;
+      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)i * 128);
+    }
+  };
+  issue_chunk(0);
+
+  // raw (un-broadened) profile at a padded pixel with wavelength lamP: voigt.c:282-292.
+  // Returns exp(-tau); the sum over lines is accumulated as Sum lead_j y_j * [Re w_j sqrt(pi)/y_j].
+  auto raw_at = [&](double lamP) -> double {
     double total = 0.0;
-    bool near = false;
     for (int j = 0; j < L; ++j) {
       const double velocity = lamP * my_mult[j] - g_lines.c;  // voigt.c:287 (two roundings)
-      const double x = fabs(velocity * g_lines.inv_sqrt2_sigma);
-      near |= x < 30.0;
-      total = fma(-g_lines.leading[j], rew_wing(x, g_lines.y[j]), total);
+      const double x = velocity * g_lines.inv_sqrt2_sigma;
+      const double x2 = x * x;
+      const double yj = g_lines.y[j];
+      double v = yj * wing_core(x2, yj * yj);
+      if (__any(x2 < 900.0))  // some lane within 30 Doppler widths of this line: accurate tier
+        v = rew_full(x, yj) * 1.7724538509055159;  // * sqrt(pi), folded back out by nscale
+      total = fma(g_lines.leading[j], v, total);
     }
-    if (__any(near)) {
-      total = 0.0;
-      for (int j = 0; j < L; ++j) {
-        const double velocity = lamP * my_mult[j] - g_lines.c;
-        total = fma(-g_lines.leading[j],
-                    rew_full(velocity * g_lines.inv_sqrt2_sigma, g_lines.y[j]), total);
-      }
-    }
-    return exp(nscale * total);  // voigt.c:291
+    return exp_nonpos(nscale * total);  // voigt.c:291
   };
 
+  __syncthreads();  // multipliers visible
   // prime the ring with padded pixels 0..7 (K-steps -2 and -1)
-  my_ring[jj] = raw_at(jj);
-  my_ring[4 + jj] = raw_at(4 + jj);
+  my_ring[jj] = raw_at(lam[min(jj, n_pad - 1)]);
+  my_ring[4 + jj] = raw_at(lam[min(4 + jj, n_pad - 1)]);
 
   d4 acc[NTW];
 #pragma unroll
   for (int c = 0; c < NTW; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
-  double quad_sum = 0.0, logd_sum = 0.0;
+  double quad_sum = 0.0, dprod = 1.0;
+  int dexp = 0;
   const int tile0 = role * NTW;
+  const double tap0 = g_lines.taps[0], tap1 = g_lines.taps[1], tap2 = g_lines.taps[2],
+               tap3 = g_lines.taps[3];
 
-  for (int c0 = 0; c0 < m.steps; c0 += kChunkSteps) {
-    const int csteps = min(kChunkSteps, m.steps - c0);
-    __syncthreads();  // previous chunk fully consumed
-    {
-      const double2 *src =
-          reinterpret_cast<const double2 *>(a.pm + ((m.pix_off / 4) + c0) * (int64_t)ntiles * 64);
-      double2 *dst = reinterpret_cast<double2 *>(pm_s);
-      const int n2 = csteps * ntiles * 32;
-      for (int e = tid; e < n2; e += 256) dst[e] = src[e];
-    }
-    __syncthreads();
-    for (int t = c0; t < c0 + csteps; ++t) {
+  __builtin_amdgcn_s_waitcnt(0);  // chunk 0 landed (vmcnt(0))
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) issue_chunk(c + 1);  // lands in the other buffer while we compute
+    const int csteps = min(kChunkSteps, m.steps - c * kChunkSteps);
+    const double *buf = stage + (size_t)(c & 1) * kChunkSteps * RD;
+    for (int tt = 0; tt < csteps; ++tt) {
+      const int t = c * kChunkSteps + tt;
+      const double *rec = buf + (size_t)tt * RD;
+      const double *extra = rec + ntiles * 64;
       // (1) raw profile two K-steps ahead -> ring
       const int P = 4 * (t + 2) + jj;
-      const double raw = raw_at(P);
+      const double raw = raw_at(extra[16 + jj]);
       my_ring[P & 15] = raw;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // (2) instrument broadening for pixel p = 4t + jj: voigt.c:297-299
+      // (2) instrument broadening for pixel p = 4t + jj: voigt.c:297-299 (symmetric taps)
       const int p = 4 * t + jj;
-      double absorb = 0.0;
-#pragma unroll
-      for (int kk = 0; kk < 7; ++kk) absorb = fma(my_ring[(p + kk) & 15], g_lines.taps[kk], absorb);
+      double absorb = my_ring[p & 15] * tap0;
+      absorb = fma(my_ring[(p + 1) & 15], tap1, absorb);
+      absorb = fma(my_ring[(p + 2) & 15], tap2, absorb);
+      absorb = fma(my_ring[(p + 3) & 15], tap3, absorb);
+      absorb = fma(my_ring[(p + 4) & 15], tap2, absorb);
+      absorb = fma(my_ring[(p + 5) & 15], tap1, absorb);
+      absorb = fma(my_ring[(p + 6) & 15], tap0, absorb);
       __builtin_amdgcn_wave_barrier();
       if (is_null) absorb = 1.0;
       // (3) weights: process_qsos.m:192-198 folded into log_mvnpdf_low_rank.m:11-15
-      const PixelRow px = pix[p];
-      const double r = fma(-absorb, px.mu, px.y);
+      const double py = extra[4 * jj], pmu = extra[4 * jj + 1], pom = extra[4 * jj + 2],
+                   pnu = extra[4 * jj + 3];
+      const double r = fma(-absorb, pmu, py);
       const double a2 = absorb * absorb;
-      const double d = fma(px.omega2, a2, px.nu);
-      const double inv_d = 1.0 / d;
+      const double d = fma(pom, a2, pnu);
+      const double inv_d = fast_rcp(d);
       const double w = a2 * inv_d;
       const double u = absorb * r * inv_d;
       quad_sum = fma(r * r, inv_d, quad_sum);
-      logd_sum += log(d);
+      dprod *= d;  // Sum log d as log of a running product, renormalised every step
+      dexp += __builtin_amdgcn_frexp_exp(dprod);
+      dprod = __builtin_amdgcn_frexp_mant(dprod);
       // (4) rank-4 update of [B | v] on the matrix cores
-      const double *bt = pm_s + (size_t)(t - c0) * ntiles * 64 + lane;
+      const double *bt = rec + lane;
 #pragma unroll
-      for (int c = 0; c < NTW; ++c) {
-        const int tile = tile0 + c;
+      for (int cc = 0; cc < NTW; ++cc) {
+        const int tile = tile0 + cc;
         if (tile < ntiles) {
           const double b = bt[(size_t)tile * 64];
-          acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(tile < a.tiles_w ? w : u, b, acc[c], 0, 0, 0);
+          acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(tile < a.tiles_w ? w : u, b, acc[cc], 0, 0, 0);
         }
       }
     }
+    __syncthreads();  // (waits vmcnt(0) for the prefetched chunk first)
   }
   // per-sample scalar sums: combine the four pixel phases jj of each sample
+  double logd_sum = log(dprod) + (double)dexp * 0.6931471805599453;
   quad_sum += __shfl_xor(quad_sum, 16);
   quad_sum += __shfl_xor(quad_sum, 32);
   logd_sum += __shfl_xor(logd_sum, 16);
   logd_sum += __shfl_xor(logd_sum, 32);
 
-  // ---- epilogue: k x k Cholesky + forward solve per sample, in LDS --------------------------
-  __syncthreads();  // everyone is done with the loop's LDS
+  // ---- epilogue: (k+1) x (k+1) column Cholesky of [[I + B, v], [v', .]] per sample -----------
+  // Four rounds (MFMA result register r = 0..3).  In round r the 16 lanes of row jj hold, in
+  // register r of every tile, the 16*ntiles columns of sample jj + 4r: they spill them to LDS and
+  // factor that sample together, lane s taking rows j+1+s, j+1+s+16 of each column j.  Row k of
+  // the augmented matrix is v, so its factor row is z = L^-1 v.
   const int ncols = ntiles * 16;
-  constexpr int ES = kSamplesPerWave + 1;  // padded sample stride
-  double *E = smem + (size_t)group * ncols * ES;  // [ncols][17]
-  // MFMA C/D layout (f64 16x16x4): lane l, register r -> row (l >> 4) + 4 r, column l & 15.
+  const int k = a.k;
+  const int voff = a.tiles_w * 16;
+  double *Eg = stage + (size_t)group * 4 * ncols;  // [4 samples][ncols] for this sample group
 #pragma unroll
-  for (int c = 0; c < NTW; ++c) {
-    const int tile = tile0 + c;
-    if (tile < ntiles) {
+  for (int r = 0; r < 4; ++r) {
+    if (TS > 1) __syncthreads();
+    double *e = Eg + (size_t)jj * ncols;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) E[(size_t)(tile * 16 + s) * ES + jj + 4 * r] = acc[c][r];
+    for (int cc = 0; cc < NTW; ++cc) {
+      const int tile = tile0 + cc;
+      if (tile < ntiles) e[tile * 16 + s] = acc[cc][r];
     }
-  }
-  __syncthreads();
-  if (role == 0 && jj == 0) {
-    const int k = a.k;
-    double *col = E + s;  // this sample's entries: col[c * ES]
-    double *vv = col + (size_t)a.tiles_w * 16 * ES;
-    double log_diag = 0.0, zz = 0.0;
-    bool pd = true;
-    for (int i = 0; i < k; ++i) {
-      const int ri = i * (i + 1) / 2;
-      for (int j = 0; j <= i; ++j) {
+    if (TS > 1) __syncthreads();
+    else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // scalars of sample jj + 4r live in the lanes whose s equals jj + 4r
+    const int src_lane = (jj + 4 * r) + 16 * jj;
+    const double q_s = __shfl(quad_sum, src_lane);
+    const double ld_s = __shfl(logd_sum, src_lane);
+    const int64_t slot_s = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave + jj + 4 * r;
+    const int32_t sample_s = __shfl(sample, src_lane);
+    if (role == 0) {
+      double lprod = 1.0, zz = 0.0;
+      bool pd = true;
+      for (int j = 0; j < k; ++j) {
         const int rj = j * (j + 1) / 2;
-        double sum = col[(size_t)(ri + j) * ES] + (i == j ? 1.0 : 0.0);  // log_mvnpdf_low_rank.m:22-23
-        for (int mm = 0; mm < j; ++mm)
-          sum = fma(-col[(size_t)(ri + mm) * ES], col[(size_t)(rj + mm) * ES], sum);
-        if (i == j) {                                                    // :24
-          pd = pd && (sum > 0.0);
-          const double lii = sqrt(sum);
-          log_diag += log(lii);
-          col[(size_t)(ri + j) * ES] = lii;
-        } else {
-          col[(size_t)(ri + j) * ES] = sum / col[(size_t)(rj + j) * ES];
+        double dj = e[rj + j] + 1.0;  // log_mvnpdf_low_rank.m:22-23
+        for (int mm = 0; mm < j; ++mm) {
+          const double t = e[rj + mm];
+          dj = fma(-t, t, dj);
         }
+        pd = pd && (dj > 0.0);
+        const double ljj = sqrt(dj);  // :24
+        const double inv = 1.0 / ljj;
+        lprod *= ljj;
+        for (int i = j + 1 + s; i <= k; i += 16) {
+          const int ri = (i < k) ? i * (i + 1) / 2 : voff;
+          double t = e[ri + j];
+          for (int mm = 0; mm < j; ++mm) t = fma(-e[ri + mm], e[rj + mm], t);
+          t *= inv;
+          e[ri + j] = t;
+          if (i == k) zz = fma(t, t, zz);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
-      double zi = vv[(size_t)i * ES];  // forward solve L z = v
-      for (int mm = 0; mm < i; ++mm) zi = fma(-col[(size_t)(ri + mm) * ES], vv[(size_t)mm * ES], zi);
-      zi /= col[(size_t)(ri + i) * ES];
-      vv[(size_t)i * ES] = zi;
-      zz = fma(zi, zi, zz);
+      zz += __shfl_xor(zz, 1);
+      zz += __shfl_xor(zz, 2);
+      zz += __shfl_xor(zz, 4);
+      zz += __shfl_xor(zz, 8);
+      if (s == 0) {
+        // log_mvnpdf_low_rank.m:30-32
+        const double log_det = ld_s + 2 * log(lprod);
+        double ll = -0.5 * ((q_s - zz) + log_det + (double)m.n_kept * kLog2Pi);
+        if (!pd) ll = NAN;
+        if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
+        else if (slot_s == a.S) a.ll_no_dla[q] = ll;
+      }
     }
-    // log_mvnpdf_low_rank.m:30-32
-    const double log_det = logd_sum + 2 * log_diag;
-    double ll = -0.5 * ((quad_sum - zz) + log_det + (double)m.n_kept * kLog2Pi);
-    if (!pd) ll = NAN;
-    if (is_sample) a.sample_ll[(int64_t)q * a.S + sample] = ll;
-    else if (slot == a.S) a.ll_no_dla[q] = ll;
   }
 }
 
