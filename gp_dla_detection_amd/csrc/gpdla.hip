@@ -354,8 +354,9 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   b->nq = nq;
   b->S = c->S;
   b->k = c->model.k;
-  b->tiles_w = (b->k * (b->k + 1) / 2 + 15) / 16;
-  b->ntiles = b->tiles_w + (b->k + 15) / 16;
+  // tile classes of the sweep kernel: k <= 20 -> 14 + 2 tiles, k <= 40 -> 52 + 4 tiles
+  b->tiles_w = b->k <= 20 ? 14 : 52;
+  b->ntiles = b->k <= 20 ? 16 : 56;
   const int64_t base = sp->offsets[0];
   b->total_pix = sp->offsets[nq] - base;
   std::vector<int64_t> off(nq + 1);
@@ -408,7 +409,7 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
 
 namespace {
 
-template <int NTW, int TS, int CH>
+template <int NTW, int TS, int CH, int TW, int LINES>
 int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   constexpr int groups = kSweepWaves / TS;
   const int L = args.num_lines;
@@ -419,13 +420,13 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   const size_t lds = (stage_doubles + (size_t)kSweepWaves * kSamplesPerWave * kRingStride +
                       (size_t)groups * kSamplesPerWave * L) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "sweep needs %zu B of LDS", lds);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<NTW, TS, CH>),
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<NTW, TS, CH, TW, LINES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   args.blocks_per_quasar = (int32_t)((b->S + 1 + groups * kSamplesPerWave - 1) / (groups * kSamplesPerWave));
   const int64_t nblocks = 8 * ((b->nq + 7) / 8) * (int64_t)args.blocks_per_quasar;
   if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "batch too large for one launch");
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  hipLaunchKernelGGL((k_sweep<NTW, TS, CH>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  hipLaunchKernelGGL((k_sweep<NTW, TS, CH, TW, LINES>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
   HIP_TRY(hipGetLastError());
   if (c->timing) {
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -505,10 +506,11 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.ll_no_dla = b->d_ll_no;
   int rc;
   sa.blocks_per_quasar = 0;  // set by launch_sweep
-  if (b->ntiles <= 16) {
-    rc = launch_sweep<16, 1, 4>(c, b, sa);
-  } else if (b->ntiles <= 56) {
-    rc = launch_sweep<14, 4, 1>(c, b, sa);
+  const bool three = cfg.num_lines == 3;
+  if (b->k <= 20) {  // 14 w-tiles (<= 210 vech columns) + 2 u-tiles, zero-padded
+    rc = three ? launch_sweep<16, 1, 4, 14, 3>(c, b, sa) : launch_sweep<16, 1, 4, 14, 0>(c, b, sa);
+  } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles, split over 4 waves
+    rc = three ? launch_sweep<14, 4, 1, 52, 3>(c, b, sa) : launch_sweep<14, 4, 1, 52, 0>(c, b, sa);
   } else {
     rc = fail(GPDLA_ERR_UNSUPPORTED, "k = %d needs %d B tiles (max 56)", b->k, b->ntiles);
   }

@@ -389,10 +389,48 @@ __device__ __forceinline__ void glds16(const double *gsrc, double *lds_wave_base
       (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-template <int NTW, int TS, int kChunkSteps>
+// Sum over the Lyman lines of lead_j * Re w_j * sqrt(pi) at one padded pixel (voigt.c:285-289).
+// LINES > 0: constants and multipliers live in registers (arrays indexed by unrolled j);
+// LINES == 0: run-time line count, constants from __constant__ memory, multipliers from LDS.
+template <int LINES>
+__device__ __forceinline__ double line_sum(double lamP, const double *mult, int L, double c_light,
+                                           double inv_s, const double *ly, const double *ly2,
+                                           const double *llead) {
+  double total = 0.0;
+  if (LINES > 0) {
+#pragma unroll
+    for (int j = 0; j < LINES; ++j) {
+      const double velocity = lamP * mult[j] - c_light;  // voigt.c:287 (two roundings)
+      const double x = velocity * inv_s;
+      const double x2 = x * x;
+      double v = ly[j] * wing_core(x2, ly2[j]);
+      if (__builtin_expect(__any(x2 < 900.0), 0))  // a lane within 30 Doppler widths of the line
+        v = rew_full(x, ly[j]) * 1.7724538509055159;  // accurate tier (* sqrt(pi))
+      total = fma(llead[j], v, total);
+    }
+  } else {
+    for (int j = 0; j < L; ++j) {
+      const double velocity = lamP * mult[j] - c_light;
+      const double x = velocity * inv_s;
+      const double x2 = x * x;
+      const double yj = g_lines.y[j];
+      double v = yj * wing_core(x2, yj * yj);
+      if (__builtin_expect(__any(x2 < 900.0), 0)) v = rew_full(x, yj) * 1.7724538509055159;
+      total = fma(g_lines.leading[j], v, total);
+    }
+  }
+  return total;
+}
+
+// Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk,
+// TW tiles that take the weight w (the rest take u; TS*NTW tiles in all, zero-padded), LINES
+// number of Lyman lines when known at compile time (0: read num_lines at run time).
+template <int NTW, int TS, int kChunkSteps, int TW, int LINES>
 __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   extern __shared__ double smem[];
   constexpr int GROUPS = kSweepWaves / TS;  // sample groups per block
+  constexpr int NT = NTW * TS;
+  constexpr int RD = NT * 64 + 32;
   const int64_t xj = blockIdx.x >> 3;
   const int64_t q = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
   const int bq = (int)(xj % a.blocks_per_quasar);
@@ -402,15 +440,14 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int group = wave / TS, role = wave % TS;
   const int s = lane & 15, jj = lane >> 4;
-  const int L = a.num_lines;
-  const int ntiles = a.ntiles;
-  const int RD = ntiles * 64 + 32;
+  const int L = LINES > 0 ? LINES : a.num_lines;
 
   double *stage = smem;                                            // [2][kChunkSteps][RD]
   double *ring = stage + (size_t)2 * kChunkSteps * RD;             // [8 waves][16][17]
   double *mult_s = ring + kSweepWaves * kSamplesPerWave * kRingStride;  // [GROUPS*16][L]
 
-  const int64_t slot = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave + s;
+  const int64_t slot0 = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave;
+  const int64_t slot = slot0 + s;
   const bool is_sample = slot < a.S;
   const bool is_null = !is_sample;  // slot == S is the null model; slots beyond it are idle copies
   const int32_t sample = is_sample ? a.perm[slot] : 0;
@@ -418,9 +455,13 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   const double z_dla = m.min_z_dla + (m.max_z_dla - m.min_z_dla) * a.offset_samples[sample];
   const double nhi = a.nhi_samples[sample];
   double *my_mult = mult_s + (size_t)(group * kSamplesPerWave + s) * L;
-  if (role == 0 && jj == 0) {
-    for (int j = 0; j < L; ++j)  // voigt.c:278-279
-      my_mult[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
+  double mult_r[LINES > 0 ? LINES : 1];
+  if (LINES > 0) {
+#pragma unroll
+    for (int j = 0; j < LINES; ++j)  // voigt.c:278-279
+      mult_r[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
+  } else if (role == 0 && jj == 0) {
+    for (int j = 0; j < L; ++j) my_mult[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
   }
   double *my_ring = ring + (size_t)(wave * kSamplesPerWave + s) * kRingStride;
   const double *lam = a.lam_pad + m.lam_off;
@@ -443,27 +484,24 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   };
   issue_chunk(0);
 
-  // raw (un-broadened) profile at a padded pixel with wavelength lamP: voigt.c:282-292.
-  // Returns exp(-tau); the sum over lines is accumulated as Sum lead_j y_j * [Re w_j sqrt(pi)/y_j].
-  auto raw_at = [&](double lamP) -> double {
-    double total = 0.0;
-    for (int j = 0; j < L; ++j) {
-      const double velocity = lamP * my_mult[j] - g_lines.c;  // voigt.c:287 (two roundings)
-      const double x = velocity * g_lines.inv_sqrt2_sigma;
-      const double x2 = x * x;
-      const double yj = g_lines.y[j];
-      double v = yj * wing_core(x2, yj * yj);
-      if (__any(x2 < 900.0))  // some lane within 30 Doppler widths of this line: accurate tier
-        v = rew_full(x, yj) * 1.7724538509055159;  // * sqrt(pi), folded back out by nscale
-      total = fma(g_lines.leading[j], v, total);
-    }
-    return exp_nonpos(nscale * total);  // voigt.c:291
-  };
+  // per-line constants in registers (LINES > 0)
+  double ly[LINES > 0 ? LINES : 1], ly2[LINES > 0 ? LINES : 1], llead[LINES > 0 ? LINES : 1];
+#pragma unroll
+  for (int j = 0; j < (LINES > 0 ? LINES : 0); ++j) {
+    ly[j] = g_lines.y[j];
+    ly2[j] = ly[j] * ly[j];
+    llead[j] = g_lines.leading[j];
+  }
+  const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
+  const double *mult_p = LINES > 0 ? mult_r : my_mult;
+  // raw (un-broadened) profile exp(-tau) at a padded pixel: voigt.c:282-292
+#define GPDLA_RAW_AT(lamP) \
+  exp_nonpos(nscale * line_sum<LINES>((lamP), mult_p, L, c_light, inv_s, ly, ly2, llead))
 
   __syncthreads();  // multipliers visible
   // prime the ring with padded pixels 0..7 (K-steps -2 and -1)
-  my_ring[jj] = raw_at(lam[min(jj, n_pad - 1)]);
-  my_ring[4 + jj] = raw_at(lam[min(4 + jj, n_pad - 1)]);
+  my_ring[jj] = GPDLA_RAW_AT(lam[min(jj, n_pad - 1)]);
+  my_ring[4 + jj] = GPDLA_RAW_AT(lam[min(4 + jj, n_pad - 1)]);
 
   d4 acc[NTW];
 #pragma unroll
@@ -471,6 +509,7 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   double quad_sum = 0.0, dprod = 1.0;
   int dexp = 0;
   const int tile0 = role * NTW;
+  const int nw = TS == 1 ? TW : max(0, min(NTW, TW - tile0));  // w-tiles of this wave
   const double tap0 = g_lines.taps[0], tap1 = g_lines.taps[1], tap2 = g_lines.taps[2],
                tap3 = g_lines.taps[3];
 
@@ -484,10 +523,15 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
     for (int tt = 0; tt < csteps; ++tt) {
       const int t = c * kChunkSteps + tt;
       const double *rec = buf + (size_t)tt * RD;
-      const double *extra = rec + ntiles * 64;
+      const double *extra = rec + NT * 64;
       // (1) raw profile two K-steps ahead -> ring
       const int P = 4 * (t + 2) + jj;
-      const double raw = raw_at(extra[16 + jj]);
+      const double raw = GPDLA_RAW_AT(extra[16 + jj]);
+      // this step's B operands: issue the LDS reads now, consume after the weights are ready
+      double bop[NTW];
+      const double *bt = rec + (size_t)tile0 * 64 + lane;
+#pragma unroll
+      for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
       my_ring[P & 15] = raw;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -516,15 +560,9 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
       dexp += __builtin_amdgcn_frexp_exp(dprod);
       dprod = __builtin_amdgcn_frexp_mant(dprod);
       // (4) rank-4 update of [B | v] on the matrix cores
-      const double *bt = rec + lane;
 #pragma unroll
-      for (int cc = 0; cc < NTW; ++cc) {
-        const int tile = tile0 + cc;
-        if (tile < ntiles) {
-          const double b = bt[(size_t)tile * 64];
-          acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(tile < a.tiles_w ? w : u, b, acc[cc], 0, 0, 0);
-        }
-      }
+      for (int cc = 0; cc < NTW; ++cc)
+        acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? w : u, bop[cc], acc[cc], 0, 0, 0);
     }
     __syncthreads();  // (waits vmcnt(0) for the prefetched chunk first)
   }
@@ -535,24 +573,22 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   logd_sum += __shfl_xor(logd_sum, 16);
   logd_sum += __shfl_xor(logd_sum, 32);
 
+#undef GPDLA_RAW_AT
   // ---- epilogue: (k+1) x (k+1) column Cholesky of [[I + B, v], [v', .]] per sample -----------
   // Four rounds (MFMA result register r = 0..3).  In round r the 16 lanes of row jj hold, in
-  // register r of every tile, the 16*ntiles columns of sample jj + 4r: they spill them to LDS and
+  // register r of every tile, the 16*NT columns of sample jj + 4r: they spill them to LDS and
   // factor that sample together, lane s taking rows j+1+s, j+1+s+16 of each column j.  Row k of
   // the augmented matrix is v, so its factor row is z = L^-1 v.
-  const int ncols = ntiles * 16;
+  constexpr int ncols = NT * 16;
   const int k = a.k;
-  const int voff = a.tiles_w * 16;
+  constexpr int voff = TW * 16;
   double *Eg = stage + (size_t)group * 4 * ncols;  // [4 samples][ncols] for this sample group
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (TS > 1) __syncthreads();
     double *e = Eg + (size_t)jj * ncols;
 #pragma unroll
-    for (int cc = 0; cc < NTW; ++cc) {
-      const int tile = tile0 + cc;
-      if (tile < ntiles) e[tile * 16 + s] = acc[cc][r];
-    }
+    for (int cc = 0; cc < NTW; ++cc) e[(tile0 + cc) * 16 + s] = acc[cc][r];
     if (TS > 1) __syncthreads();
     else {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -562,7 +598,7 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
     const int src_lane = (jj + 4 * r) + 16 * jj;
     const double q_s = __shfl(quad_sum, src_lane);
     const double ld_s = __shfl(logd_sum, src_lane);
-    const int64_t slot_s = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave + jj + 4 * r;
+    const int64_t slot_s = slot0 + jj + 4 * r;
     const int32_t sample_s = __shfl(sample, src_lane);
     if (role == 0) {
       double lprod = 1.0, zz = 0.0;
