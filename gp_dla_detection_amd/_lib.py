@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgpdla.so")
+# GPDLA_LIB_PATH: diagnostic override (ablation builds made by tools/ablate.sh)
+LIB_PATH = os.environ.get("GPDLA_LIB_PATH") or os.path.join(CSRC, "libgpdla.so")
 
 # -no-hip-rt: libgpdla.so does NOT carry its own DT_NEEDED on libamdhip64.  A process must hold
 # exactly one HIP runtime (a second copy cannot open the GPU, and a hipStream_t only means

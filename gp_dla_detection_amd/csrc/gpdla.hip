@@ -73,6 +73,9 @@ int ensure_line_table(int device_id) {
     t.wavelength_cm[i] = wl[i];
     t.leading[i] = lead[i];
     t.y[i] = gam[i] / std::sqrt(2.0) / sigma;
+    t.y2[i] = t.y[i] * t.y[i];
+    t.cwing[i] = lead[i] * t.y[i];
+    t.m2y2[i] = -2.0 * t.y2[i];
   }
   for (int i = 0; i < 7; ++i) t.taps[i] = taps[i];
   t.c = GPDLA_SPEED_OF_LIGHT_CGS;

@@ -41,6 +41,9 @@ struct LineTable {
   double wavelength_cm[kMaxLines];  // voigt.c:31
   double leading[kMaxLines];        // voigt.c:151
   double y[kMaxLines];              // gamma_j / (sqrt2 sigma): damping parameter of w(z)
+  double y2[kMaxLines];             // y_j^2
+  double cwing[kMaxLines];          // leading_j * y_j            (wing formula prefactor)
+  double m2y2[kMaxLines];           // -2 y_j^2                   (wing formula correction)
   double taps[7];                   // voigt.c:242-251
   double c;                         // voigt.c:22
   double inv_sqrt2_sigma;           // 1/(sqrt2 sigma)
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
   un_min = block_reduce_minmax(un_min, true, s_red);
   un_max = block_reduce_minmax(un_max, false, s_red);
   const int steps = (n_u + 3) >> 2;
-  // pad rows up to 4*steps: neutral pixels
-  for (int u = n_u + tid; u < 4 * steps; u += 256) {
+  // pad rows up to 4*(steps+1): neutral pixels (the last 4 feed the neutral trailing record)
+  for (int u = n_u + tid; u < 4 * steps + 4; u += 256) {
     pix[u] = PixelRow{0.0, 0.0, 0.0, 1.0};
     for (int c = 0; c < k; ++c) Mi[(int64_t)u * k + c] = 0.0;
   }
@@ -238,7 +241,8 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
 //                    idx(i, j) = i(i+1)/2 + j, j <= i).  The first tiles_w = ceil(k(k+1)/2 / 16)
 //                    tiles take the weight w, the following ceil(k/16) tiles take u.
 //   [+0, +16)        PixelRow (y, mu, omega2, nu) of pixels 4t .. 4t+3
-//   [+16, +20)       padded wavelengths 4(t+2) .. 4(t+2)+3 (the raw profile runs two steps ahead)
+//   [+16, +20)       padded wavelengths 4(t+3) .. 4(t+3)+3 (the raw profile runs three steps ahead)
+// Record `steps` (one past the last K-step) is neutral: zero tiles, (y, mu, omega2, nu) = (0,0,0,1).
 //   [+20, +32)       unused (keeps records 16-byte granular and 256-byte aligned)
 // ------------------------------------------------------------------------------------------
 struct BuildRecordsArgs {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
   const int bq = blockIdx.x % a.blocks_per_quasar;
   const QuasarMeta m = a.meta[q];
   const int RD = record_doubles(a.ntiles);
-  const int64_t total = (int64_t)m.steps * RD;
+  const int64_t total = (int64_t)(m.steps + 1) * RD;
   const int ncol_w = a.k * (a.k + 1) / 2;
   const int n_pad = m.n_u + 6;
   double *out = a.records + (m.pix_off / 4) * (int64_t)RD;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
         const int f = r2 & 3;
         v = f == 0 ? px.y : f == 1 ? px.mu : f == 2 ? px.omega2 : px.nu;
       } else if (r2 < 20) {
-        int P = 4 * (step + 2) + (r2 - 16);
+        int P = 4 * (step + 3) + (r2 - 16);
         if (P > n_pad - 1) P = n_pad - 1;
         v = a.lam_pad[m.lam_off + P];
       }
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
 // are reused by the Cholesky epilogue.
 // ------------------------------------------------------------------------------------------
 constexpr int kSweepWaves = 8;
+constexpr int kValuPerMfma = 10;  // VALU instructions scheduled behind each MFMA of the main loop
 
 struct SweepArgs {
   const QuasarMeta *meta;
@@ -392,34 +397,71 @@ __device__ __forceinline__ void glds16(const double *gsrc, double *lds_wave_base
 // Sum over the Lyman lines of lead_j * Re w_j * sqrt(pi) at one padded pixel (voigt.c:285-289).
 // LINES > 0: constants and multipliers live in registers (arrays indexed by unrolled j);
 // LINES == 0: run-time line count, constants from __constant__ memory, multipliers from LDS.
-template <int LINES>
+// ACCURATE = false: branch-free wing formula for every line; *near is set when this lane is
+// within 30 Doppler widths of some line centre (the wing formula is then not valid).
+// ACCURATE = true: the three-tier rew_full for every line.
+template <int LINES, bool ACCURATE>
 __device__ __forceinline__ double line_sum(double lamP, const double *mult, int L, double c_light,
                                            double inv_s, const double *ly, const double *ly2,
-                                           const double *llead) {
+                                           const double *llead, bool *near) {
   double total = 0.0;
+  bool nr = false;
   if (LINES > 0) {
 #pragma unroll
     for (int j = 0; j < LINES; ++j) {
       const double velocity = lamP * mult[j] - c_light;  // voigt.c:287 (two roundings)
       const double x = velocity * inv_s;
-      const double x2 = x * x;
-      double v = ly[j] * wing_core(x2, ly2[j]);
-      if (__builtin_expect(__any(x2 < 900.0), 0))  // a lane within 30 Doppler widths of the line
-        v = rew_full(x, ly[j]) * 1.7724538509055159;  // accurate tier (* sqrt(pi))
+      double v;
+      if (ACCURATE) {
+        v = rew_full(x, ly[j]) * 1.7724538509055159;  // * sqrt(pi)
+      } else {
+        const double x2 = x * x;
+        nr |= x2 < 900.0;
+        v = ly[j] * wing_core(x2, ly2[j]);
+      }
       total = fma(llead[j], v, total);
     }
   } else {
     for (int j = 0; j < L; ++j) {
       const double velocity = lamP * mult[j] - c_light;
       const double x = velocity * inv_s;
-      const double x2 = x * x;
       const double yj = g_lines.y[j];
-      double v = yj * wing_core(x2, yj * yj);
-      if (__builtin_expect(__any(x2 < 900.0), 0)) v = rew_full(x, yj) * 1.7724538509055159;
+      double v;
+      if (ACCURATE) {
+        v = rew_full(x, yj) * 1.7724538509055159;
+      } else {
+        const double x2 = x * x;
+        nr |= x2 < 900.0;
+        v = yj * wing_core(x2, yj * yj);
+      }
       total = fma(g_lines.leading[j], v, total);
     }
   }
+  if (near) *near = nr;
   return total;
+}
+
+// Accurate tier of the raw profile, out of line on purpose: it runs for ~5 % of the K-steps, and
+// inlining its register footprint into the pipelined main loop spills the accumulators.
+template <int LINES>
+__device__ __noinline__ double raw_accurate(double lamP, double m0, double m1, double m2,
+                                            const double *mult_lds, int L, double nscale) {
+  const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
+  double total = 0.0;
+  if (LINES > 0) {
+    const double mm[3] = {m0, m1, m2};
+#pragma unroll
+    for (int j = 0; j < (LINES > 0 ? LINES : 1); ++j) {
+      const double velocity = lamP * mm[j < 3 ? j : 0] - c_light;  // voigt.c:287
+      total = fma(g_lines.leading[j], rew_full(velocity * inv_s, g_lines.y[j]), total);
+    }
+  } else {
+    for (int j = 0; j < L; ++j) {
+      const double velocity = lamP * mult_lds[j] - c_light;
+      total = fma(g_lines.leading[j], rew_full(velocity * inv_s, g_lines.y[j]), total);
+    }
+  }
+  return exp_nonpos(nscale * 1.7724538509055159 * total);  // voigt.c:291
 }
 
 // Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk,
@@ -469,11 +511,13 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   // exp(N * total / (sqrt(2 pi) sigma)) with total = -Sum lead_j Re w_j (voigt.c:288-291)
   const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
   const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
-  const int nchunks = (m.steps + kChunkSteps - 1) / kChunkSteps;
 
-  // asynchronous global -> LDS copy of one chunk of records (1 KiB per wave-instruction)
+  // asynchronous global -> LDS copy of one chunk of records (1 KiB per wave-instruction).
+  // A quasar has steps + 1 records; the last one is neutral (zero tiles, d = 1).
+  const int nrec = m.steps + 1;
+  const int nchunks = (nrec + kChunkSteps - 1) / kChunkSteps;
   auto issue_chunk = [&](int c) {
-    const int csteps = min(kChunkSteps, m.steps - c * kChunkSteps);
+    const int csteps = min(kChunkSteps, nrec - c * kChunkSteps);
     const int units = csteps * (RD / 2);  // 16-byte units
     const double *src = rec_base + (size_t)c * kChunkSteps * RD;
     double *dst = stage + (size_t)(c & 1) * kChunkSteps * RD;
@@ -489,19 +533,21 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
 #pragma unroll
   for (int j = 0; j < (LINES > 0 ? LINES : 0); ++j) {
     ly[j] = g_lines.y[j];
-    ly2[j] = ly[j] * ly[j];
+    ly2[j] = g_lines.y2[j];
     llead[j] = g_lines.leading[j];
   }
   const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
   const double *mult_p = LINES > 0 ? mult_r : my_mult;
-  // raw (un-broadened) profile exp(-tau) at a padded pixel: voigt.c:282-292
-#define GPDLA_RAW_AT(lamP) \
-  exp_nonpos(nscale * line_sum<LINES>((lamP), mult_p, L, c_light, inv_s, ly, ly2, llead))
+  // raw (un-broadened) profile exp(-tau) at a padded pixel, accurate tier: voigt.c:282-292
+#define GPDLA_RAW_ACCURATE(lamP)                                                            \
+  raw_accurate<LINES>((lamP), mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], \
+                      my_mult, L, nscale)
 
   __syncthreads();  // multipliers visible
-  // prime the ring with padded pixels 0..7 (K-steps -2 and -1)
-  my_ring[jj] = GPDLA_RAW_AT(lam[min(jj, n_pad - 1)]);
-  my_ring[4 + jj] = GPDLA_RAW_AT(lam[min(4 + jj, n_pad - 1)]);
+  // prime the ring with padded pixels 0..11 (the raw profile runs three K-steps ahead)
+  my_ring[jj] = GPDLA_RAW_ACCURATE(lam[min(jj, n_pad - 1)]);
+  my_ring[4 + jj] = GPDLA_RAW_ACCURATE(lam[min(4 + jj, n_pad - 1)]);
+  my_ring[8 + jj] = GPDLA_RAW_ACCURATE(lam[min(8 + jj, n_pad - 1)]);
 
   d4 acc[NTW];
 #pragma unroll
@@ -515,57 +561,207 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
 
   __builtin_amdgcn_s_waitcnt(0);  // chunk 0 landed (vmcnt(0))
   __syncthreads();
+  if (nchunks > 1) issue_chunk(1);
 
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) issue_chunk(c + 1);  // lands in the other buffer while we compute
-    const int csteps = min(kChunkSteps, m.steps - c * kChunkSteps);
-    const double *buf = stage + (size_t)(c & 1) * kChunkSteps * RD;
-    for (int tt = 0; tt < csteps; ++tt) {
-      const int t = c * kChunkSteps + tt;
-      const double *rec = buf + (size_t)tt * RD;
-      const double *extra = rec + NT * 64;
-      // (1) raw profile two K-steps ahead -> ring
-      const int P = 4 * (t + 2) + jj;
-      const double raw = GPDLA_RAW_AT(extra[16 + jj]);
-      // this step's B operands: issue the LDS reads now, consume after the weights are ready
-      double bop[NTW];
-      const double *bt = rec + (size_t)tile0 * 64 + lane;
-#pragma unroll
-      for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
-      my_ring[P & 15] = raw;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // (2) instrument broadening for pixel p = 4t + jj: voigt.c:297-299 (symmetric taps)
-      const int p = 4 * t + jj;
-      double absorb = my_ring[p & 15] * tap0;
-      absorb = fma(my_ring[(p + 1) & 15], tap1, absorb);
-      absorb = fma(my_ring[(p + 2) & 15], tap2, absorb);
-      absorb = fma(my_ring[(p + 3) & 15], tap3, absorb);
-      absorb = fma(my_ring[(p + 4) & 15], tap2, absorb);
-      absorb = fma(my_ring[(p + 5) & 15], tap1, absorb);
-      absorb = fma(my_ring[(p + 6) & 15], tap0, absorb);
-      __builtin_amdgcn_wave_barrier();
-      if (is_null) absorb = 1.0;
-      // (3) weights: process_qsos.m:192-198 folded into log_mvnpdf_low_rank.m:11-15
-      const double py = extra[4 * jj], pmu = extra[4 * jj + 1], pom = extra[4 * jj + 2],
-                   pnu = extra[4 * jj + 3];
-      const double r = fma(-absorb, pmu, py);
-      const double a2 = absorb * absorb;
-      const double d = fma(pom, a2, pnu);
-      const double inv_d = fast_rcp(d);
-      const double w = a2 * inv_d;
-      const double u = absorb * r * inv_d;
-      quad_sum = fma(r * r, inv_d, quad_sum);
-      dprod *= d;  // Sum log d as log of a running product, renormalised every step
+  // Software pipeline.  prep(record r) produces everything step r's MFMAs need -- weights (w, u)
+  // and the 16 B-operand fragments -- plus the raw profile three steps ahead.  Iteration t issues
+  // the MFMAs of step t next to prep(record t+1); the two are independent, so the matrix pipe and
+  // the VALU run concurrently inside one wave.  The accurate Faddeeva tier (rare) is a fix-up at
+  // the top of the NEXT iteration (the ring entry it corrects is first read there), which keeps
+  // MFMAs + prep one straight-line block for the scheduler.
+  double w_cur, u_cur, bop[NTW];
+  bool near_c = false;   // carried to the next iteration: this lane's newest ring entry needs
+  double lam_c = 0.0;    // the accurate tier (wavelength lam_c, ring slot slot_c)
+  int slot_c = 0;
+#define GPDLA_PREP(rec, r_index)                                                                  \
+  const double *extra_ = (rec) + NT * 64;                                                         \
+  const double lamP_ = extra_[16 + jj];                                                           \
+  bool near_;                                                                                     \
+  double raw_ = exp_nonpos(nscale * line_sum<LINES, false>(lamP_, mult_p, L, c_light, inv_s, ly,  \
+                                                             ly2, llead, &near_));                \
+  const int p_ = 4 * (r_index) + jj;                                                              \
+  double absorb_ = my_ring[p_ & 15] * tap0;                                                       \
+  absorb_ = fma(my_ring[(p_ + 1) & 15], tap1, absorb_);                                           \
+  absorb_ = fma(my_ring[(p_ + 2) & 15], tap2, absorb_);                                           \
+  absorb_ = fma(my_ring[(p_ + 3) & 15], tap3, absorb_);                                           \
+  absorb_ = fma(my_ring[(p_ + 4) & 15], tap2, absorb_);                                           \
+  absorb_ = fma(my_ring[(p_ + 5) & 15], tap1, absorb_);                                           \
+  absorb_ = fma(my_ring[(p_ + 6) & 15], tap0, absorb_);                                           \
+  if (is_null) absorb_ = 1.0;                                                                     \
+  const double py_ = extra_[4 * jj], pmu_ = extra_[4 * jj + 1], pom_ = extra_[4 * jj + 2],        \
+               pnu_ = extra_[4 * jj + 3];                                                         \
+  const double r_ = fma(-absorb_, pmu_, py_);                                                     \
+  const double a2_ = absorb_ * absorb_;                                                           \
+  const double d_ = fma(pom_, a2_, pnu_);                                                         \
+  const double inv_d_ = fast_rcp(d_);                                                             \
+  w_cur = a2_ * inv_d_;                                                                           \
+  u_cur = absorb_ * r_ * inv_d_;                                                                  \
+  quad_sum = fma(r_ * r_, inv_d_, quad_sum);                                                      \
+  dprod *= d_; /* Sum log d as the log of a running product, renormalised every step */           \
+  dexp += __builtin_amdgcn_frexp_exp(dprod);                                                      \
+  dprod = __builtin_amdgcn_frexp_mant(dprod);                                                     \
+  {                                                                                               \
+    const double *bt_ = (rec) + (size_t)tile0 * 64 + lane;                                        \
+    _Pragma("unroll") for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt_[(size_t)cc * 64];            \
+  }                                                                                               \
+  near_c = near_;                                                                                 \
+  lam_c = lamP_;                                                                                  \
+  slot_c = (p_ + 12) & 15;                                                                        \
+  my_ring[slot_c] = raw_;
+
+  {
+    GPDLA_PREP(stage, 0)
+  }
+  for (int t = 0; t < m.steps; ++t) {
+    const int rn = t + 1;  // record prepared in this iteration
+    const int cn = rn / kChunkSteps;
+    if (rn % kChunkSteps == 0) {   // entering a new chunk: it must have landed in LDS
+      __syncthreads();             // (emits s_waitcnt vmcnt(0) first); chunk cn-1 is now free
+      if (cn + 1 < nchunks) issue_chunk(cn + 1);
+    }
+    const double *rec = stage + ((size_t)(cn & 1) * kChunkSteps + (rn % kChunkSteps)) * RD;
+    // fix-up of the ring entries written by the previous prep with the wing formula although
+    // some lane sat within 30 Doppler widths of a line centre (first read by the conv below)
+    if (__builtin_expect(__any(near_c), 0)) my_ring[slot_c] = GPDLA_RAW_ACCURATE(lam_c);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double wa = w_cur, ua = u_cur;
+    if constexpr (LINES == 3) {
+      // ---- hand-staged block: MFMA cc of step t, then ~10 VALU of prep(record t+1) in its
+      // 64-cycle shadow; sched_barrier(0) pins the interleave (the compiler otherwise issues the
+      // 16 MFMAs back to back and the matrix pipe idles during the VALU work).
+#define MF(cc)                                                                               \
+  if constexpr ((cc) < NTW)                                                                  \
+    acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64((cc) < nw ? wa : ua, bop[cc], acc[cc], 0, 0, 0);
+#define BREAD(cc)                                                                            \
+  if constexpr ((cc) < NTW) bop[cc] = bt_[(size_t)(cc) * 64];
+#define SB __builtin_amdgcn_sched_barrier(0)
+      const double *extra_ = rec + NT * 64;
+      const double *bt_ = rec + (size_t)tile0 * 64 + lane;
+      const int p_ = 4 * rn + jj;
+      const double lamP_ = extra_[16 + jj];
+      SB;
+      MF(0)  // S0: velocities -> x^2 + y^2 per line (voigt.c:287), reciprocal seeds
+      const double xa = (lamP_ * mult_r[0] - c_light) * inv_s, xb = (lamP_ * mult_r[1] - c_light) * inv_s,
+                   xc = (lamP_ * mult_r[2] - c_light) * inv_s;
+      const double x2a = xa * xa, x2b = xb * xb, x2c = xc * xc;
+      const double sa = x2a + ly2[0], sb = x2b + ly2[1], sc = x2c + ly2[2];
+      double ra = __builtin_amdgcn_rcp(sa), rb = __builtin_amdgcn_rcp(sb), rc = __builtin_amdgcn_rcp(sc);
+      const bool near_ = (x2a < 900.0) | (x2b < 900.0) | (x2c < 900.0);  // accurate tier needed
+      SB;
+      MF(1)  // S1: two Newton steps per reciprocal
+      BREAD(0) BREAD(1)
+      double ea = fma(-sa, ra, 1.0), eb = fma(-sb, rb, 1.0), ec = fma(-sc, rc, 1.0);
+      ra = fma(ra, ea, ra); rb = fma(rb, eb, rb); rc = fma(rc, ec, rc);
+      ea = fma(-sa, ra, 1.0); eb = fma(-sb, rb, 1.0); ec = fma(-sc, rc, 1.0);
+      ra = fma(ra, ea, ra); rb = fma(rb, eb, rb); rc = fma(rc, ec, rc);
+      SB;
+      MF(2)  // S2: wing series T(rho), upper half
+      double ta = fma(kT6, ra, kT5), tb = fma(kT6, rb, kT5), tc = fma(kT6, rc, kT5);
+      ta = fma(ta, ra, kT4); tb = fma(tb, rb, kT4); tc = fma(tc, rc, kT4);
+      ta = fma(ta, ra, kT3); tb = fma(tb, rb, kT3); tc = fma(tc, rc, kT3);
+      SB;
+      MF(3)  // S3: lower half
+      BREAD(2) BREAD(3)
+      ta = fma(ta, ra, kT2); tb = fma(tb, rb, kT2); tc = fma(tc, rc, kT2);
+      ta = fma(ta, ra, kT1); tb = fma(tb, rb, kT1); tc = fma(tc, rc, kT1);
+      ta = fma(ta, ra, kT0); tb = fma(tb, rb, kT0); tc = fma(tc, rc, kT0);
+      SB;
+      MF(4)  // S4: - 2 y^2 rho^2 correction, times rho
+      ta = fma(g_lines.m2y2[0] * ra, ra, ta); tb = fma(g_lines.m2y2[1] * rb, rb, tb);
+      tc = fma(g_lines.m2y2[2] * rc, rc, tc);
+      const double va = ra * ta, vb = rb * tb, vc = rc * tc;
+      SB;
+      MF(5)  // S5: optical depth, exp range reduction
+      BREAD(4) BREAD(5)
+      double ex = nscale * fma(g_lines.cwing[2], vc, fma(g_lines.cwing[1], vb, g_lines.cwing[0] * va));
+      ex = fmax(ex, -800.0);
+      const double en = rint(ex * 1.4426950408889634);
+      double er = fma(-en, 0.6931471803691238, ex);
+      er = fma(-en, 1.9082149292705877e-10, er);
+      SB;
+      MF(6)  // S6: exp Taylor polynomial, degree 12, upper half; ring taps for S8 requested
+      const double g0 = my_ring[p_ & 15], g1 = my_ring[(p_ + 1) & 15], g2 = my_ring[(p_ + 2) & 15],
+                   g3 = my_ring[(p_ + 3) & 15], g4 = my_ring[(p_ + 4) & 15],
+                   g5 = my_ring[(p_ + 5) & 15], g6 = my_ring[(p_ + 6) & 15];
+      double ep = 2.08767569878681e-09;
+      ep = fma(ep, er, 2.505210838544172e-08);
+      ep = fma(ep, er, 2.755731922398589e-07);
+      ep = fma(ep, er, 2.755731922398589e-06);
+      ep = fma(ep, er, 2.48015873015873e-05);
+      ep = fma(ep, er, 0.0001984126984126984);
+      ep = fma(ep, er, 0.001388888888888889);
+      SB;
+      MF(7)  // S7: lower half, scale by 2^n -> raw profile three steps ahead (voigt.c:291)
+      BREAD(6) BREAD(7)
+      const double py_ = extra_[4 * jj], pmu_ = extra_[4 * jj + 1], pom_ = extra_[4 * jj + 2],
+                   pnu_ = extra_[4 * jj + 3];
+      ep = fma(ep, er, 0.008333333333333333);
+      ep = fma(ep, er, 0.041666666666666664);
+      ep = fma(ep, er, 0.16666666666666666);
+      ep = fma(ep, er, 0.5);
+      ep = fma(ep, er, 1.0);
+      ep = fma(ep, er, 1.0);
+      const double raw_ = ldexp(ep, (int)en);
+      SB;
+      MF(8)  // S8: instrument broadening of pixel 4 rn + jj (voigt.c:297-299, symmetric taps)
+      double absorb_ = fma(g6, tap0, g0 * tap0);
+      double ab2 = fma(g5, tap1, g1 * tap1);
+      absorb_ = fma(g2, tap2, absorb_);
+      ab2 = fma(g4, tap2, ab2);
+      absorb_ = fma(g3, tap3, absorb_);
+      absorb_ += ab2;
+      if (is_null) absorb_ = 1.0;
+      SB;
+      MF(9)  // S9: residual, diagonal, its reciprocal (process_qsos.m:192-198)
+      BREAD(8) BREAD(9)
+      const double r_ = fma(-absorb_, pmu_, py_);
+      const double a2_ = absorb_ * absorb_;
+      const double d_ = fma(pom_, a2_, pnu_);
+      double inv_d_ = __builtin_amdgcn_rcp(d_);
+      double ed = fma(-d_, inv_d_, 1.0);
+      inv_d_ = fma(inv_d_, ed, inv_d_);
+      ed = fma(-d_, inv_d_, 1.0);
+      inv_d_ = fma(inv_d_, ed, inv_d_);
+      SB;
+      MF(10)  // S10: MFMA weights of step rn, quadratic form and log-det accumulators
+      w_cur = a2_ * inv_d_;
+      u_cur = absorb_ * r_ * inv_d_;
+      quad_sum = fma(r_ * r_, inv_d_, quad_sum);
+      dprod *= d_;
       dexp += __builtin_amdgcn_frexp_exp(dprod);
       dprod = __builtin_amdgcn_frexp_mant(dprod);
-      // (4) rank-4 update of [B | v] on the matrix cores
+      near_c = near_;
+      lam_c = lamP_;
+      slot_c = (p_ + 12) & 15;
+      my_ring[slot_c] = raw_;
+      SB;
+      MF(11)
+      BREAD(10) BREAD(11)
+      SB;
+      MF(12)
+      SB;
+      MF(13)
+      BREAD(12) BREAD(13)
+      SB;
+      MF(14)
+      SB;
+      MF(15)
+      BREAD(14) BREAD(15)
+      SB;
+#undef MF
+#undef BREAD
+#undef SB
+    } else {
+      // generic line count: MFMAs of step t, then the unstaged prep
 #pragma unroll
       for (int cc = 0; cc < NTW; ++cc)
-        acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? w : u, bop[cc], acc[cc], 0, 0, 0);
+        acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? wa : ua, bop[cc], acc[cc], 0, 0, 0);
+      GPDLA_PREP(rec, rn)
     }
-    __syncthreads();  // (waits vmcnt(0) for the prefetched chunk first)
   }
+  __syncthreads();  // everyone is done with the stage buffers
+#undef GPDLA_PREP
   // per-sample scalar sums: combine the four pixel phases jj of each sample
   double logd_sum = log(dprod) + (double)dexp * 0.6931471805599453;
   quad_sum += __shfl_xor(quad_sum, 16);
@@ -573,7 +769,7 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   logd_sum += __shfl_xor(logd_sum, 16);
   logd_sum += __shfl_xor(logd_sum, 32);
 
-#undef GPDLA_RAW_AT
+#undef GPDLA_RAW_ACCURATE
   // ---- epilogue: (k+1) x (k+1) column Cholesky of [[I + B, v], [v', .]] per sample -----------
   // Four rounds (MFMA result register r = 0..3).  In round r the 16 lanes of row jj hold, in
   // register r of every tile, the 16*NT columns of sample jj + 4r: they spill them to LDS and
@@ -600,7 +796,16 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
     const double ld_s = __shfl(logd_sum, src_lane);
     const int64_t slot_s = slot0 + jj + 4 * r;
     const int32_t sample_s = __shfl(sample, src_lane);
+#ifdef GPDLA_ABLATE_NOEPI
+    if (role == 0 && s == 0) {
+      const double ll = q_s + ld_s + e[0];
+      if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
+      else if (slot_s == a.S) a.ll_no_dla[q] = ll;
+    }
+    if (false) {
+#else
     if (role == 0) {
+#endif
       double lprod = 1.0, zz = 0.0;
       bool pd = true;
       for (int j = 0; j < k; ++j) {
