@@ -622,7 +622,9 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
     const double *rec = stage + ((size_t)(cn & 1) * kChunkSteps + (rn % kChunkSteps)) * RD;
     // fix-up of the ring entries written by the previous prep with the wing formula although
     // some lane sat within 30 Doppler widths of a line centre (first read by the conv below)
+#ifndef GPDLA_ABLATE_NOSLOW
     if (__builtin_expect(__any(near_c), 0)) my_ring[slot_c] = GPDLA_RAW_ACCURATE(lam_c);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const double wa = w_cur, ua = u_cur;
@@ -630,9 +632,17 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
       // ---- hand-staged block: MFMA cc of step t, then ~10 VALU of prep(record t+1) in its
       // 64-cycle shadow; sched_barrier(0) pins the interleave (the compiler otherwise issues the
       // 16 MFMAs back to back and the matrix pipe idles during the VALU work).
+#ifdef GPDLA_ABLATE_NOMFMA
+#define MF(cc)                                                                               \
+  if constexpr ((cc) < NTW) {                                                                \
+    asm volatile("" ::"v"(bop[cc]));                                                         \
+    if ((cc) < 2) acc[cc][0] += ((cc) < nw ? wa : ua) * bop[cc];                             \
+  }
+#else
 #define MF(cc)                                                                               \
   if constexpr ((cc) < NTW)                                                                  \
     acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64((cc) < nw ? wa : ua, bop[cc], acc[cc], 0, 0, 0);
+#endif
 #define BREAD(cc)                                                                            \
   if constexpr ((cc) < NTW) bop[cc] = bt_[(size_t)(cc) * 64];
 #define SB __builtin_amdgcn_sched_barrier(0)
@@ -702,7 +712,11 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
       ep = fma(ep, er, 0.5);
       ep = fma(ep, er, 1.0);
       ep = fma(ep, er, 1.0);
+#ifdef GPDLA_ABLATE_NOVOIGT
+      const double raw_ = lamP_ * 1e-4;
+#else
       const double raw_ = ldexp(ep, (int)en);
+#endif
       SB;
       MF(8)  // S8: instrument broadening of pixel 4 rn + jj (voigt.c:297-299, symmetric taps)
       double absorb_ = fma(g6, tap0, g0 * tap0);
