@@ -15,10 +15,14 @@
  * double gamma)  (libcerf is NOT in /root/reference and its version is not pinned anywhere,
  * README.md:210-218).  libcerf documents voigt(x,sigma,gamma) = Re w((x + i gamma)/(sqrt2 sigma))
  * / (sqrt(2 pi) sigma); that published definition is restated here with this file's own Faddeeva
- * routine.  PARITY PIN: the Voigt half is pinned against golden vectors produced by importing the
- * reference's own CDDF_analysis/voigt.py (scipy wofz) in the build container
- * (tests/golden/make_golden.py); the MATLAB half cannot run anywhere here (no MATLAB/Octave), so
- * it is pinned by construction (line-by-line restatement) plus an independent dense evaluation.
+ * routine.
+ *
+ * PARITY PIN.  Voigt half: PINNED against golden vectors produced by importing the reference's own
+ * CDDF_analysis/voigt.py (scipy wofz) in the build container (tests/golden/make_golden.py).
+ * MATLAB half (log_mvnpdf_low_rank.m, process_qsos.m, the multi-DLA driver): PARITY UNPINNED -- no
+ * MATLAB/Octave exists in this pipeline and the reference ships no tests or fixtures, so no
+ * reference-produced number exists for it; it is a line-by-line restatement cross-checked against an
+ * independent dense evaluation and an independent NumPy restatement (tests/test_oracle_driver.py).
  */
 #ifndef GPDLA_ORACLE_H
 #define GPDLA_ORACLE_H
