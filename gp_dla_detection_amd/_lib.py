@@ -60,7 +60,8 @@ class Config(C.Structure):
                 ("min_z_cut", C.c_double), ("width", C.c_int32), ("num_lines", C.c_int32),
                 ("max_dlas", C.c_int32), ("num_forest_lines", C.c_int32),
                 ("min_z_separation", C.c_double), ("prev_tau_0", C.c_double),
-                ("prev_beta", C.c_double)]
+                ("prev_beta", C.c_double), ("rng_seed", C.c_uint64),
+                ("first_quasar_index", C.c_int64)]
 
 
 class Results(C.Structure):
@@ -77,7 +78,7 @@ class ResultsMulti(C.Structure):
         "sample_log_likelihoods_lls", "log_likelihoods_dla", "log_likelihoods_lls",
         "log_posteriors_no_dla", "log_posteriors_lls", "log_posteriors_dla", "model_posteriors",
         "p_no_dlas", "p_lls", "p_dlas", "MAP_z_dlas", "MAP_log_nhis", "MAP_inds")] + [
-        ("status", _i32p)]
+        ("base_sample_inds", _u32p), ("status", _i32p)]
 
 
 #: every symbol include/gpdla.h declares: (name, restype, argtypes)

@@ -9,6 +9,8 @@ reference                                  here
 ``log_mvnpdf_low_rank(y, mu, M, d)``       :func:`log_mvnpdf_low_rank`        (log_mvnpdf_low_rank.m:5)
 DLA-existence prior of the driver          :func:`dla_existence_prior`        (process_qsos.m:122-131)
 ``process_qsos`` script                    :func:`process_qsos`               (process_qsos.m:88-244)
+``process_qsos_multiple_dlas_meanflux``    :func:`process_qsos_multiple_dlas_meanflux`
+                                                                              (multi_dlas/...m:141-510)
 =========================================  =====================================================
 
 plus :class:`Context` / :class:`Batch` for callers that keep spectra resident in HBM (what
@@ -22,7 +24,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .parameters import Parameters
+from .parameters import MultiParameters, Parameters
 
 _dp = C.POINTER(C.c_double)
 
@@ -39,7 +41,8 @@ def _config(params: Parameters) -> _lib.Config:
     for name in ("min_lambda", "max_lambda", "lya_wavelength", "lyman_limit", "pixel_spacing",
                  "max_z_cut", "min_z_cut", "width", "num_lines"):
         setattr(cfg, name, getattr(params, name))
-    for name in ("max_dlas", "num_forest_lines", "min_z_separation", "prev_tau_0", "prev_beta"):
+    for name in ("max_dlas", "num_forest_lines", "min_z_separation", "prev_tau_0", "prev_beta",
+                 "rng_seed", "first_quasar_index"):
         if hasattr(params, name):
             setattr(cfg, name, getattr(params, name))
     return cfg
@@ -315,4 +318,111 @@ def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None
     out["num_lines"] = p.num_lines
     out["prior_z_qso_increase"] = p.prior_z_qso_increase
     out["max_z_cut"] = p.max_z_cut
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# multi-DLA driver
+# ----------------------------------------------------------------------------------------------
+
+def dla_existence_prior_multi(prior_z_qsos, prior_dla_ind, z_qsos, Z_lls: float, Z_dla: float,
+                              params: MultiParameters | None = None):
+    """process_qsos_multiple_dlas_meanflux.m:189-216: priors for exactly 1..max_dlas DLAs
+    ((M/N)^k - (M/N)^(k+1)), for a sub-DLA (M/N * Z_lls/Z_dla) and for no absorber.
+    Returns (log_priors_no_dla [nq], log_priors_lls [nq], log_priors_dla [nq, max_dlas])."""
+    p = params or MultiParameters()
+    pz = np.asarray(prior_z_qsos, dtype=np.float64)
+    pd = np.asarray(prior_dla_ind, dtype=bool)
+    z = np.atleast_1d(np.asarray(z_qsos, dtype=np.float64))
+    order = np.argsort(pz, kind="stable")
+    cum = np.concatenate([[0], np.cumsum(pd[order])])
+    N = np.searchsorted(pz[order], z + p.prior_z_qso_increase, side="left").astype(np.float64)
+    M = cum[N.astype(np.int64)].astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pk = (M / N)[:, None] ** np.arange(1, p.max_dlas + 1)[None, :]      # :194
+        pk[:, :-1] = pk[:, :-1] - pk[:, 1:]                                  # :197-199
+        log_dla = np.log(pk)                                                 # :204
+        log_lls = np.log(M) - np.log(N) + np.log(Z_lls) - np.log(Z_dla)      # :208-210
+        log_no = np.log(N - M - Z_lls * M / Z_dla) - np.log(N)               # :214-216
+    return log_no, log_lls, log_dla
+
+
+def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log_priors,
+                                        params: MultiParameters | None = None,
+                                        base_sample_inds=None, device: int = 0) -> dict:
+    """The multi-DLA driver (multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-510).
+
+    ``samples`` additionally carries ``log_nhi_samples`` and ``lls_nhi_samples``
+    (set_lls_parameters.m:59-63).  ``log_priors = (no_dla [nq], lls [nq], dla [nq, max_dlas])`` as
+    returned by :func:`dla_existence_prior_multi`.  ``base_sample_inds``: optional uint32
+    ``[nq, max_dlas-1, S]``, 1-based (the reference's saved variable, :476, transposed to
+    quasar-slowest); when omitted the resampling of :467-472 is drawn on the GPU (Philox4x32-10,
+    ``params.rng_seed``).  Returns the variables the script saves (:498-510); 3-D arrays are
+    ``sample_log_likelihoods_dla [nq, max_dlas, S]`` and ``MAP_* [nq, model, slot]``."""
+    lib = _lib.load()
+    p = params or MultiParameters()
+    csr = spectra if isinstance(spectra, dict) else spectra_to_csr(spectra)
+    nq, md = csr["z_qsos"].size, p.max_dlas
+    keep = []
+
+    def ptr(a, dt, ct):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data_as(C.POINTER(ct))
+
+    rw, rwp = _f64(model["rest_wavelengths"])
+    mu, mup = _f64(model["mu"])
+    Mf = np.asfortranarray(model["M"], dtype=np.float64)
+    lo, lop = _f64(model["log_omega"])
+    m = _lib.Model(rw.size, Mf.shape[1], rwp, mup, Mf.ctypes.data_as(_dp), lop,
+                   float(model["log_c_0"]), float(model["log_tau_0"]), float(model["log_beta"]))
+    S = np.asarray(samples["offset_samples"]).size
+    sm = _lib.Samples(S, ptr(samples["offset_samples"], np.float64, C.c_double),
+                      ptr(samples["log_nhi_samples"], np.float64, C.c_double),
+                      ptr(samples["nhi_samples"], np.float64, C.c_double),
+                      ptr(samples["lls_nhi_samples"], np.float64, C.c_double))
+    lp_no, lp_lls, lp_dla = log_priors
+    sp = _lib.Spectra(nq, ptr(csr["offsets"], np.int64, C.c_int64),
+                      ptr(csr["wavelengths"], np.float64, C.c_double),
+                      ptr(csr["flux"], np.float64, C.c_double),
+                      ptr(csr["noise_variance"], np.float64, C.c_double),
+                      ptr(csr["pixel_mask"], np.uint8, C.c_uint8),
+                      ptr(csr["z_qsos"], np.float64, C.c_double),
+                      ptr(lp_no, np.float64, C.c_double),
+                      ptr(np.asarray(lp_dla).reshape(nq, md), np.float64, C.c_double),
+                      ptr(lp_lls, np.float64, C.c_double))
+    cfg = _config(p)
+    out = {
+        "min_z_dlas": np.full(nq, np.nan), "max_z_dlas": np.full(nq, np.nan),
+        "log_likelihoods_no_dla": np.full(nq, np.nan),
+        "sample_log_likelihoods_dla": np.full((nq, md, S), np.nan),
+        "sample_log_likelihoods_lls": np.full((nq, S), np.nan),
+        "log_likelihoods_dla": np.full((nq, md), np.nan), "log_likelihoods_lls": np.full(nq, np.nan),
+        "log_posteriors_no_dla": np.full(nq, np.nan), "log_posteriors_lls": np.full(nq, np.nan),
+        "log_posteriors_dla": np.full((nq, md), np.nan),
+        "model_posteriors": np.full((nq, 2 + md), np.nan),
+        "p_no_dlas": np.full(nq, np.nan), "p_lls": np.full(nq, np.nan), "p_dlas": np.full(nq, np.nan),
+        "MAP_z_dlas": np.full((nq, md, md), np.nan), "MAP_log_nhis": np.full((nq, md, md), np.nan),
+        "MAP_inds": np.full((nq, md, md), np.nan),
+        "base_sample_inds": np.zeros((nq, max(md - 1, 1), S), dtype=np.uint32),
+        "status": np.zeros(nq, dtype=np.int32),
+    }
+    r = _lib.ResultsMulti()
+    for name, _ in _lib.ResultsMulti._fields_:
+        ct = {"status": C.c_int32, "base_sample_inds": C.c_uint32}.get(name, C.c_double)
+        setattr(r, name, out[name].ctypes.data_as(C.POINTER(ct)))
+    base_ptr = None
+    if base_sample_inds is not None:
+        base = np.ascontiguousarray(base_sample_inds, dtype=np.uint32)
+        if base.shape != (nq, md - 1, S):
+            raise _lib.GpdlaError(-1, f"base_sample_inds must be [nq, max_dlas-1, S], got {base.shape}")
+        keep.append(base)
+        base_ptr = base.ctypes.data_as(C.POINTER(C.c_uint32))
+    _lib.check(lib.gpdla_process_batch_multi(C.byref(m), C.byref(sm), C.byref(sp), base_ptr,
+                                             C.byref(cfg), C.byref(r), int(device)))
+    out["log_priors_no_dla"], out["log_priors_lls"], out["log_priors_dla"] = (
+        np.asarray(lp_no), np.asarray(lp_lls), np.asarray(lp_dla).reshape(nq, md))
+    out["all_exceptions"] = np.where(out["status"] == 1, 1.0, np.nan)  # multi :139, :232
+    if md > 1:
+        out["base_sample_inds"] = out["base_sample_inds"][:, : md - 1]
     return out

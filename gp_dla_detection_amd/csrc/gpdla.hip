@@ -15,7 +15,7 @@
 
 #include "../../include/gpdla.h"
 #include "../../include/gpdla_lyman_series.h"
-#include "sweep_kernels.hpp"
+#include "multi_kernels.hpp"
 
 using namespace gpdla;
 
@@ -64,14 +64,17 @@ int ensure_line_table(int device_id) {
 #define GP_WL(i, wl, f, G, lead, gam) wl,
 #define GP_LEAD(i, wl, f, G, lead, gam) lead,
 #define GP_GAM(i, wl, f, G, lead, gam) gam,
+#define GP_OSC(i, wl, f, G, lead, gam) f,
   const double wl[] = {GPDLA_LYMAN_SERIES(GP_WL)};
   const double lead[] = {GPDLA_LYMAN_SERIES(GP_LEAD)};
   const double gam[] = {GPDLA_LYMAN_SERIES(GP_GAM)};
+  const double osc[] = {GPDLA_LYMAN_SERIES(GP_OSC)};
   const double taps[] = GPDLA_INSTRUMENT_PROFILE;
   const double sigma = GPDLA_GAUSS_SIGMA_CGS;
   for (int i = 0; i < kMaxLines; ++i) {
     t.wavelength_cm[i] = wl[i];
     t.leading[i] = lead[i];
+    t.osc[i] = osc[i];
     t.y[i] = gam[i] / std::sqrt(2.0) / sigma;
     t.y2[i] = t.y[i] * t.y[i];
     t.cwing[i] = lead[i] * t.y[i];
@@ -166,6 +169,8 @@ void gpdla_default_config(gpdla_config *cfg) {
   cfg->min_z_separation = 3000 * kms;       // multi :33
   cfg->prev_tau_0 = 0.0023;                 // multi :36
   cfg->prev_beta = 3.65;                    // multi :37
+  cfg->rng_seed = 0x9E3779B97F4A7C15ull;
+  cfg->first_quasar_index = 0;
 }
 
 /* ------------------------------ context ------------------------------ */
@@ -442,11 +447,12 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
 
 extern "C" {
 
-int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
-  if (!c || !b || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
-  if (b->S != c->S || b->k != c->model.k)
-    return fail(GPDLA_ERR_INVALID_ARGUMENT, "model/samples changed after the batch was uploaded");
-  HIP_TRY(hipSetDevice(c->device_id));
+}  // extern "C"
+
+namespace {
+
+// k_prepare + k_build_records for a batch (multi: the mean-flux / Lyman-series variant)
+int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi) {
   hipStream_t st = c->stream;
   Config cfg;
   cfg.min_lambda = c->cfg.min_lambda;
@@ -457,7 +463,6 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   cfg.max_z_cut = c->cfg.max_z_cut;
   cfg.min_z_cut = c->cfg.min_z_cut;
   cfg.num_lines = c->cfg.num_lines;
-
   PrepareArgs pa;
   pa.nq = b->nq;
   pa.offsets = b->d_offsets;
@@ -472,9 +477,12 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   pa.pix = b->d_pix;
   pa.Mi = b->d_Mi;
   pa.lam_pad = b->d_lam;
+  pa.multi = multi ? 1 : 0;
+  pa.num_forest_lines = c->cfg.num_forest_lines;
+  pa.prev_tau_0 = c->cfg.prev_tau_0;
+  pa.prev_beta = c->cfg.prev_beta;
   hipLaunchKernelGGL(k_prepare, dim3((unsigned)b->nq), dim3(256), 0, st, pa);
   HIP_TRY(hipGetLastError());
-
   BuildRecordsArgs ba;
   ba.meta = b->d_meta;
   ba.pix = b->d_pix;
@@ -487,6 +495,22 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   ba.blocks_per_quasar = 16;
   hipLaunchKernelGGL(k_build_records, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
   HIP_TRY(hipGetLastError());
+  return GPDLA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
+  if (!c || !b || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
+  if (b->S != c->S || b->k != c->model.k)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "model/samples changed after the batch was uploaded");
+  HIP_TRY(hipSetDevice(c->device_id));
+  hipStream_t st = c->stream;
+  int rc = launch_prepare(c, b, false);
+  if (rc) return rc;
+  const int num_lines = c->cfg.num_lines;
 
   // NaN pre-fill, as process_qsos.m:74-82 does for quasars that are skipped
   HIP_TRY(hipMemsetAsync(b->d_sample_ll, 0xFF, (size_t)b->nq * b->S * sizeof(double), st));
@@ -504,12 +528,11 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.k = b->k;
   sa.tiles_w = b->tiles_w;
   sa.ntiles = b->ntiles;
-  sa.num_lines = cfg.num_lines;
+  sa.num_lines = num_lines;
   sa.sample_ll = b->d_sample_ll;
   sa.ll_no_dla = b->d_ll_no;
-  int rc;
   sa.blocks_per_quasar = 0;  // set by launch_sweep
-  const bool three = cfg.num_lines == 3;
+  const bool three = num_lines == 3;
   if (b->k <= 20) {  // 14 w-tiles (<= 210 vech columns) + 2 u-tiles, zero-padded
     rc = three ? launch_sweep<16, 1, 4, 14, 3>(c, b, sa) : launch_sweep<16, 1, 4, 14, 0>(c, b, sa);
   } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles, split over 4 waves
@@ -676,9 +699,268 @@ int gpdla_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M
   return GPDLA_OK;
 }
 
-int gpdla_process_batch_multi(const gpdla_model *, const gpdla_samples *, const gpdla_spectra *,
-                              const uint32_t *, const gpdla_config *, gpdla_results_multi *, int) {
-  return fail(GPDLA_ERR_UNSUPPORTED, "multi-DLA driver not built yet");
+}  // extern "C"
+
+namespace {
+
+template <int NTW, int TS, int CH, int TW>
+int launch_sweep_multi(gpdla_context *c, gpdla_batch *b, SweepMultiArgs args) {
+  constexpr int groups = kSweepWaves / TS;
+  const size_t RD = (size_t)b->ntiles * 64 + 32;
+  const size_t lds = 2 * (size_t)CH * RD * sizeof(double);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_multi<NTW, TS, CH, TW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.blocks_per_quasar = (int32_t)((args.S + 1 + groups * kSamplesPerWave - 1) / (groups * kSamplesPerWave));
+  const int64_t nblocks = 8 * (((int64_t)args.nq_sub + 7) / 8) * (int64_t)args.blocks_per_quasar;
+  if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "sub-batch too large for one launch");
+  hipLaunchKernelGGL((k_sweep_multi<NTW, TS, CH, TW>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  HIP_TRY(hipGetLastError());
+  return GPDLA_OK;
+}
+
+struct MultiBuffers {
+  double *sll_dla = nullptr, *sll_lls = nullptr, *ll_no = nullptr, *ll_dla = nullptr, *ll_lls = nullptr;
+  double *map_z = nullptr, *map_n = nullptr, *map_i = nullptr, *prof = nullptr;
+  double *lp_lls = nullptr, *lp_dla = nullptr;
+  double *post = nullptr, *scal = nullptr;  // scal: lpost_no, lpost_lls, p_no, p_lls, p_dla [5][nq]; lpost_dla after
+  uint32_t *base = nullptr;
+  int32_t *alive = nullptr;
+  ~MultiBuffers() {
+    for (void *p : {(void *)sll_dla, (void *)sll_lls, (void *)ll_no, (void *)ll_dla, (void *)ll_lls,
+                    (void *)map_z, (void *)map_n, (void *)map_i, (void *)prof, (void *)lp_lls,
+                    (void *)lp_dla, (void *)post, (void *)scal, (void *)base, (void *)alive})
+      dev_free(p);
+  }
+};
+
+int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const uint32_t *base_in,
+              gpdla_results_multi *r) {
+  const int64_t nq = b->nq, S = b->S;
+  const int md = c->cfg.max_dlas;
+  if (md < 1 || md > 4) return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d outside [1, 4]", md);
+  if (!c->d_lls_nhi || !c->d_log_nhi)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs lls_nhi_samples and log_nhi_samples");
+  if (!sp->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
+  hipStream_t st = c->stream;
+  int rc = launch_prepare(c, b, true);
+  if (rc) return rc;
+  MultiBuffers mb;
+  auto chk = [&](int x) { if (x && !rc) rc = x; };
+  const size_t nqs = (size_t)nq;
+  chk(dev_alloc(&mb.sll_dla, nqs * md * S));
+  chk(dev_alloc(&mb.sll_lls, nqs * S));
+  chk(dev_alloc(&mb.ll_no, nqs));
+  chk(dev_alloc(&mb.ll_dla, nqs * md));
+  chk(dev_alloc(&mb.ll_lls, nqs));
+  chk(dev_alloc(&mb.map_z, nqs * md * md));
+  chk(dev_alloc(&mb.map_n, nqs * md * md));
+  chk(dev_alloc(&mb.map_i, nqs * md * md));
+  chk(dev_alloc(&mb.base, nqs * (md > 1 ? md - 1 : 1) * S));
+  chk(dev_alloc(&mb.alive, nqs));
+  chk(upload(&mb.lp_lls, sp->log_priors_lls, nqs, st));
+  chk(upload(&mb.lp_dla, sp->log_priors_dla, nqs * md, st));
+  chk(dev_alloc(&mb.post, nqs * (2 + md)));
+  chk(dev_alloc(&mb.scal, nqs * (5 + md)));
+  if (rc) return rc;
+  // NaN pre-fill (multi :110-131); alive = 1; base = 0 (multi :116) or the caller's indices
+  HIP_TRY(hipMemsetAsync(mb.sll_dla, 0xFF, nqs * md * S * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(mb.sll_lls, 0xFF, nqs * S * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(mb.ll_no, 0xFF, nqs * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(mb.ll_dla, 0xFF, nqs * md * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(mb.ll_lls, 0xFF, nqs * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(mb.map_z, 0xFF, nqs * md * md * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(mb.map_n, 0xFF, nqs * md * md * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(mb.map_i, 0xFF, nqs * md * md * sizeof(double), st));
+  {
+    std::vector<int32_t> ones(nqs, 1);
+    HIP_TRY(hipMemcpyAsync(mb.alive, ones.data(), nqs * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  const size_t nbase = nqs * (md > 1 ? md - 1 : 0) * S;
+  if (base_in && nbase)
+    HIP_TRY(hipMemcpyAsync(mb.base, base_in, nbase * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  else
+    HIP_TRY(hipMemsetAsync(mb.base, 0, (nbase ? nbase : 1) * sizeof(uint32_t), st));
+
+  // profile table: rows of `stride` doubles, 2 S rows per quasar, sub-batches sized to ~16 GiB
+  int64_t max_rows = 0;
+  for (int64_t q = 0; q < nq; ++q) max_rows = std::max(max_rows, sp->offsets[q + 1] - sp->offsets[q]);
+  const int64_t stride = ((4 * ((max_rows + 3) / 4) + 4 + 15) / 16) * 16;
+  const double per_q = 2.0 * (double)S * (double)stride * sizeof(double);
+  int64_t nq_sub = (int64_t)std::max(1.0, std::floor(16.0 * 1073741824.0 / per_q));
+  nq_sub = std::min(nq_sub, nq);
+  chk(dev_alloc(&mb.prof, (size_t)nq_sub * 2 * S * stride));
+  if (rc) return rc;
+  const double log_S = std::log((double)S);
+
+  for (int64_t q0 = 0; q0 < nq; q0 += nq_sub) {
+    const int32_t nsub = (int32_t)std::min(nq_sub, nq - q0);
+    ProfilesArgs pa;
+    pa.meta = b->d_meta;
+    pa.lam_pad = b->d_lam;
+    pa.offset_samples = c->d_offset;
+    pa.nhi_samples = c->d_nhi;
+    pa.lls_nhi_samples = c->d_lls_nhi;
+    pa.S = S;
+    pa.num_lines = c->cfg.num_lines;
+    pa.q0 = q0;
+    pa.nq_sub = nsub;
+    pa.stride = stride;
+    pa.prof = mb.prof;
+    const int64_t waves = (int64_t)nsub * 2 * S;
+    hipLaunchKernelGGL(k_profiles, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, pa);
+    HIP_TRY(hipGetLastError());
+    for (int mode = 0; mode <= md; ++mode) {  // LLS pass (mode 0) rides with model 1
+      if (mode == 0) continue;
+      for (int pass = (mode == 1 ? 0 : 1); pass < 2; ++pass) {
+        SweepMultiArgs sa;
+        sa.meta = b->d_meta;
+        sa.records = b->d_records;
+        sa.prof = mb.prof;
+        sa.base_inds = mb.base;
+        sa.alive = mb.alive;
+        sa.S = S;
+        sa.q0 = q0;
+        sa.stride = stride;
+        sa.nq_sub = nsub;
+        sa.blocks_per_quasar = 0;
+        sa.k = b->k;
+        sa.mode = pass == 0 ? 0 : mode;
+        sa.max_dlas = md;
+        sa.log_S = log_S;
+        sa.sample_ll_dla = mb.sll_dla;
+        sa.sample_ll_lls = mb.sll_lls;
+        sa.ll_no_dla = mb.ll_no;
+        rc = b->k <= 20 ? launch_sweep_multi<16, 1, 4, 14>(c, b, sa) : launch_sweep_multi<14, 4, 1, 52>(c, b, sa);
+        if (rc) return rc;
+      }
+      // evidence, MAP, early-exit flags for the quasars of this sub-batch
+      MultiEvidenceArgs ea;
+      ea.meta = b->d_meta + q0;
+      ea.offset_samples = c->d_offset;
+      ea.log_nhi_samples = c->d_log_nhi;
+      ea.base_inds = mb.base + (size_t)q0 * (md > 1 ? md - 1 : 0) * S;
+      ea.alive = mb.alive + q0;
+      ea.S = S;
+      ea.nd = mode;
+      ea.max_dlas = md;
+      ea.min_z_separation = c->cfg.min_z_separation;
+      ea.log_S = log_S;
+      ea.sample_ll_dla = mb.sll_dla + (size_t)q0 * md * S;
+      ea.sample_ll_lls = mb.sll_lls + (size_t)q0 * S;
+      ea.ll_dla = mb.ll_dla + (size_t)q0 * md;
+      ea.ll_lls = mb.ll_lls + q0;
+      ea.map_z = mb.map_z + (size_t)q0 * md * md;
+      ea.map_lognhi = mb.map_n + (size_t)q0 * md * md;
+      ea.map_ind = mb.map_i + (size_t)q0 * md * md;
+      hipLaunchKernelGGL(k_multi_evidence, dim3((unsigned)nsub), dim3(256), 0, st, ea);
+      HIP_TRY(hipGetLastError());
+      if (mode < md && !base_in) {  // multi :467-472
+        MultiResampleArgs ra;
+        ra.meta = b->d_meta + q0;
+        ra.alive = mb.alive + q0;
+        ra.sample_ll_dla = mb.sll_dla + (size_t)q0 * md * S;
+        ra.S = S;
+        ra.first_quasar_index = c->cfg.first_quasar_index + q0;
+        ra.seed = c->cfg.rng_seed;
+        ra.nd = mode;
+        ra.max_dlas = md;
+        ra.base_inds = mb.base + (size_t)q0 * (md - 1) * S;
+        const size_t lds = (size_t)S * sizeof(double);
+        if (lds > 150 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "resampling supports S <= 19200");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_multi_resample),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_multi_resample, dim3((unsigned)nsub), dim3(256), lds, st, ra);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+  }
+  // posteriors over (no DLA, LLS, 1..max_dlas DLAs)
+  MultiPostArgs pp;
+  pp.meta = b->d_meta;
+  pp.nq = nq;
+  pp.max_dlas = md;
+  pp.lp_no = b->d_lp_no;
+  pp.lp_lls = mb.lp_lls;
+  pp.lp_dla = mb.lp_dla;
+  pp.ll_no = mb.ll_no;
+  pp.ll_lls = mb.ll_lls;
+  pp.ll_dla = mb.ll_dla;
+  pp.lpost_no = mb.scal;
+  pp.lpost_lls = mb.scal + nqs;
+  pp.p_no = mb.scal + 2 * nqs;
+  pp.p_lls = mb.scal + 3 * nqs;
+  pp.p_dla = mb.scal + 4 * nqs;
+  pp.lpost_dla = mb.scal + 5 * nqs;
+  pp.post = mb.post;
+  hipLaunchKernelGGL(k_multi_posteriors, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, pp);
+  HIP_TRY(hipGetLastError());
+
+  // download
+  std::vector<QuasarMeta> meta(nqs);
+  HIP_TRY(hipMemcpyAsync(meta.data(), b->d_meta, nqs * sizeof(QuasarMeta), hipMemcpyDeviceToHost, st));
+  auto dl = [&](void *dst, const void *src, size_t bytes) -> int {
+    if (dst && bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+    return GPDLA_OK;
+  };
+  chk(dl(r->log_likelihoods_no_dla, mb.ll_no, nqs * 8));
+  chk(dl(r->sample_log_likelihoods_dla, mb.sll_dla, nqs * md * S * 8));
+  chk(dl(r->sample_log_likelihoods_lls, mb.sll_lls, nqs * S * 8));
+  chk(dl(r->log_likelihoods_dla, mb.ll_dla, nqs * md * 8));
+  chk(dl(r->log_likelihoods_lls, mb.ll_lls, nqs * 8));
+  chk(dl(r->log_posteriors_no_dla, pp.lpost_no, nqs * 8));
+  chk(dl(r->log_posteriors_lls, pp.lpost_lls, nqs * 8));
+  chk(dl(r->log_posteriors_dla, pp.lpost_dla, nqs * md * 8));
+  chk(dl(r->model_posteriors, mb.post, nqs * (2 + md) * 8));
+  chk(dl(r->p_no_dlas, pp.p_no, nqs * 8));
+  chk(dl(r->p_lls, pp.p_lls, nqs * 8));
+  chk(dl(r->p_dlas, pp.p_dla, nqs * 8));
+  chk(dl(r->MAP_z_dlas, mb.map_z, nqs * md * md * 8));
+  chk(dl(r->MAP_log_nhis, mb.map_n, nqs * md * md * 8));
+  chk(dl(r->MAP_inds, mb.map_i, nqs * md * md * 8));
+  chk(dl(r->base_sample_inds, mb.base, nbase * sizeof(uint32_t)));
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  for (size_t q = 0; q < nqs; ++q) {
+    if (r->min_z_dlas) r->min_z_dlas[q] = meta[q].min_z_dla;
+    if (r->max_z_dlas) r->max_z_dlas[q] = meta[q].max_z_dla;
+    if (r->status) r->status[q] = meta[q].status;
+  }
+  return GPDLA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
+                              const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
+                              const gpdla_config *config, gpdla_results_multi *results,
+                              int device_id) {
+  if (!model || !samples || !spectra || !results)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  gpdla_context *c = nullptr;
+  gpdla_batch *b = nullptr;
+  int rc = gpdla_context_create(device_id, &c);
+  if (rc) return rc;
+  gpdla_config cfg;
+  gpdla_default_config(&cfg);
+  if (config) cfg = *config;
+  // gpdla_batch_upload wants one prior per quasar for the single-DLA table; the multi driver
+  // uploads its own [nq][max_dlas] table, so hand the batch the first column only
+  gpdla_spectra sp1 = *spectra;
+  std::vector<double> first_col;
+  if (spectra->log_priors_dla && spectra->num_quasars > 0 && cfg.max_dlas >= 1) {
+    first_col.resize((size_t)spectra->num_quasars);
+    for (int64_t q = 0; q < spectra->num_quasars; ++q) first_col[q] = spectra->log_priors_dla[q * cfg.max_dlas];
+    sp1.log_priors_dla = first_col.data();
+  }
+  if (!(rc = gpdla_context_set_config(c, &cfg)) && !(rc = gpdla_context_set_model(c, model)) &&
+      !(rc = gpdla_context_set_samples(c, samples)) && !(rc = gpdla_batch_upload(c, &sp1, &b)))
+    rc = run_multi(c, b, spectra, base_sample_inds, results);
+  gpdla_batch_destroy(b);
+  gpdla_context_destroy(c);
+  return rc;
 }
 
 }  // extern "C"

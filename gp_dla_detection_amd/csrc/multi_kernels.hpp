@@ -1,0 +1,498 @@
+// multi_kernels.hpp -- device side of the multi-DLA driver
+// (multi_dlas/process_qsos_multiple_dlas_meanflux.m, "multi :N" below).
+//
+// In the multi-DLA models sample i of model nd multiplies nd Voigt profiles: its own and those of
+// the samples base_sample_inds(1:nd-1, i) (multi :342-351).  Every profile is a function of one
+// sample index alone, so the 2 S distinct profiles of a quasar (S DLA + S sub-DLA column densities,
+// multi :365-368) are computed ONCE (k_profiles) into HBM -- 288 GB holds them for hundreds of
+// quasars at a time -- and the sweeps of the 1 + max_dlas models gather and multiply them
+// (k_sweep_multi), feeding the same MFMA contraction and Cholesky epilogue as the single-DLA sweep.
+//
+//   k_profiles        voigt.c:278-299 for every (quasar, DLA|LLS, sample)
+//   k_sweep_multi     multi :340-381   (the parfor body)
+//   k_multi_evidence  multi :386-445   separation mask, nanmax/nanmean evidence, Occam terms, MAP
+//   k_multi_resample  multi :467-472   weighted resampling (documented counter-based RNG; the
+//                                      reference uses MATLAB's rng('default') + randsample)
+//   k_multi_posteriors multi :482-495
+#pragma once
+#include "sweep_kernels.hpp"
+
+namespace gpdla {
+
+// ------------------------------------------------------------------------------------------
+// k_profiles: one wave per (quasar, kind, sample); lanes run along 64 padded pixels, the 7-tap
+// broadening comes from wave shuffles, 58 outputs per pass.
+// prof[((ql * 2 + kind) * S + i) * stride + p], p < stride (>= 4 * steps; entries >= n_u are 1).
+// ------------------------------------------------------------------------------------------
+struct ProfilesArgs {
+  const QuasarMeta *meta;
+  const double *lam_pad;
+  const double *offset_samples, *nhi_samples, *lls_nhi_samples;
+  int64_t S;
+  int32_t num_lines;
+  int64_t q0;        // first quasar of this sub-batch
+  int32_t nq_sub;
+  int64_t stride;
+  double *prof;
+};
+
+__global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
+  __shared__ double s_mult[4][kMaxLines];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t w_global = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t per_q = 2 * a.S;
+  const int64_t ql = w_global / per_q;
+  if (ql >= a.nq_sub) return;
+  const int64_t rem = w_global - ql * per_q;
+  const int kind = (int)(rem / a.S);
+  const int64_t i = rem - (int64_t)kind * a.S;
+  const QuasarMeta m = a.meta[a.q0 + ql];
+  double *row = a.prof + ((ql * 2 + kind) * a.S + i) * a.stride;
+  if (m.status != 0) return;
+  const int L = a.num_lines;
+  const double z_dla = m.min_z_dla + (m.max_z_dla - m.min_z_dla) * a.offset_samples[i];  // multi :309
+  const double nhi = kind ? a.lls_nhi_samples[i] : a.nhi_samples[i];
+  if (lane < L) s_mult[wave][lane] = g_lines.c / (g_lines.wavelength_cm[lane] * (1 + z_dla)) / 1e8;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const double *lam = a.lam_pad + m.lam_off;
+  const int n_pad = m.n_u + 6;
+  const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
+  const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
+  const int nseg = (m.n_u + 57) / 58;
+  for (int seg = 0; seg < nseg; ++seg) {
+    const int P = seg * 58 + lane;
+    const double lamP = lam[min(P, n_pad - 1)];
+    double total = 0.0;
+    bool near = false;
+    for (int j = 0; j < L; ++j) {
+      const double x = (lamP * s_mult[wave][j] - c_light) * inv_s;  // voigt.c:287
+      const double x2 = x * x;
+      near |= x2 < 900.0;
+      total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
+    }
+    if (__any(near)) {
+      total = 0.0;
+      for (int j = 0; j < L; ++j) {
+        const double x = (lamP * s_mult[wave][j] - c_light) * inv_s;
+        total = fma(g_lines.leading[j], rew_full(x, g_lines.y[j]) * 1.7724538509055159, total);
+      }
+    }
+    const double raw = exp_nonpos(nscale * total);  // voigt.c:291
+    double acc = raw * g_lines.taps[0];             // voigt.c:297-299
+#pragma unroll
+    for (int kk = 1; kk < 7; ++kk) acc = fma(__shfl_down(raw, kk), g_lines.taps[kk], acc);
+    const int p = seg * 58 + lane;
+    if (lane < 58 && p < m.n_u) row[p] = acc;
+  }
+  for (int64_t p = m.n_u + lane; p < a.stride; p += 64) row[p] = 1.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep_multi: the parfor body of multi :340-381 for one model.
+// mode 0: LLS profiles (multi :365-380); mode nd >= 1: product of nd DLA profiles.
+// Slot S of the mode-1 pass is the null model (multi :296-298).
+// ------------------------------------------------------------------------------------------
+struct SweepMultiArgs {
+  const QuasarMeta *meta;
+  const double *records;
+  const double *prof;
+  const uint32_t *base_inds;   // [nq][max_dlas-1][S], 1-based (multi :116, :476)
+  const int32_t *alive;        // [nq] 0 once an evidence came out NaN (multi :460-464)
+  int64_t S, q0, stride;
+  int32_t nq_sub, blocks_per_quasar, k, mode, max_dlas;
+  double log_S;
+  double *sample_ll_dla;       // [nq][max_dlas][S]
+  double *sample_ll_lls;       // [nq][S]
+  double *ll_no_dla;           // [nq]
+};
+
+template <int NTW, int TS, int kChunkSteps, int TW>
+__global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
+  extern __shared__ double smem[];
+  constexpr int GROUPS = kSweepWaves / TS;
+  constexpr int NT = NTW * TS;
+  constexpr int RD = NT * 64 + 32;
+  const int64_t xj = blockIdx.x >> 3;
+  const int64_t ql = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
+  const int bq = (int)(xj % a.blocks_per_quasar);
+  if (ql >= a.nq_sub) return;
+  const int64_t q = a.q0 + ql;
+  const QuasarMeta m = a.meta[q];
+  if (m.status != 0 || a.alive[q] == 0) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int group = wave / TS, role = wave % TS;
+  const int s = lane & 15, jj = lane >> 4;
+  double *stage = smem;  // [2][kChunkSteps][RD]
+
+  const int64_t slot0 = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave;
+  const int64_t slot = slot0 + s;
+  const bool is_sample = slot < a.S;
+  const bool is_null = !is_sample;
+  const int64_t i = is_sample ? slot : 0;
+  const int nd = a.mode == 0 ? 1 : a.mode;
+  // rows of the profile table this lane multiplies (multi :342-351)
+  const double *rows[4];
+  rows[0] = a.prof + ((ql * 2 + (a.mode == 0 ? 1 : 0)) * a.S + i) * a.stride;
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    int64_t kk = i;
+    if (j < nd) kk = (int64_t)a.base_inds[((int64_t)q * (a.max_dlas - 1) + (j - 1)) * a.S + i] - 1;
+    rows[j] = a.prof + ((ql * 2) * a.S + kk) * a.stride;
+  }
+  const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
+  const int nrec = m.steps + 1;
+  const int nchunks = (nrec + kChunkSteps - 1) / kChunkSteps;
+  auto issue_chunk = [&](int c) {
+    const int csteps = min(kChunkSteps, nrec - c * kChunkSteps);
+    const int units = csteps * (RD / 2);
+    const double *src = rec_base + (size_t)c * kChunkSteps * RD;
+    double *dst = stage + (size_t)(c & 1) * kChunkSteps * RD;
+    for (int u = wave; u * 64 < units; u += kSweepWaves) {
+      const int unit = u * 64 + lane;
+      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)u * 128);
+    }
+  };
+  issue_chunk(0);
+  d4 acc[NTW];
+#pragma unroll
+  for (int c = 0; c < NTW; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+  double quad_sum = 0.0, dprod = 1.0;
+  int dexp = 0;
+  const int tile0 = role * NTW;
+  const int nw = TS == 1 ? TW : max(0, min(NTW, TW - tile0));
+
+  // absorption of pixel p for this lane's sample: product of the gathered profiles
+  auto absorption = [&](int p) -> double {
+    double v = rows[0][p];
+    if (nd > 1) v *= rows[1][p];
+    if (nd > 2) v *= rows[2][p];
+    if (nd > 3) v *= rows[3][p];
+    return is_null ? 1.0 : v;
+  };
+  double a_next = absorption(jj);  // step 0
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (nchunks > 1) issue_chunk(1);
+
+  double w_cur, u_cur, bop[NTW];
+#define GPDLA_MPREP(rec, absorb_in)                                                       \
+  {                                                                                       \
+    const double *extra_ = (rec) + NT * 64;                                               \
+    const double absorb_ = (absorb_in);                                                   \
+    const double py_ = extra_[4 * jj], pmu_ = extra_[4 * jj + 1], pom_ = extra_[4 * jj + 2], \
+                 pnu_ = extra_[4 * jj + 3];                                               \
+    const double r_ = fma(-absorb_, pmu_, py_);      /* multi :355 */                     \
+    const double a2_ = absorb_ * absorb_;                                                 \
+    const double d_ = fma(pom_, a2_, pnu_);          /* multi :357, :361 */               \
+    const double inv_d_ = fast_rcp(d_);                                                   \
+    w_cur = a2_ * inv_d_;                                                                 \
+    u_cur = absorb_ * r_ * inv_d_;                                                        \
+    quad_sum = fma(r_ * r_, inv_d_, quad_sum);                                            \
+    dprod *= d_;                                                                          \
+    dexp += __builtin_amdgcn_frexp_exp(dprod);                                            \
+    dprod = __builtin_amdgcn_frexp_mant(dprod);                                           \
+    const double *bt_ = (rec) + (size_t)tile0 * 64 + lane;                                \
+    _Pragma("unroll") for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt_[(size_t)cc * 64];    \
+  }
+  GPDLA_MPREP(stage, a_next)
+  for (int t = 0; t < m.steps; ++t) {
+    const int rn = t + 1;
+    const int cn = rn / kChunkSteps;
+    if (rn % kChunkSteps == 0) {
+      __syncthreads();
+      if (cn + 1 < nchunks) issue_chunk(cn + 1);
+    }
+    const double *rec = stage + ((size_t)(cn & 1) * kChunkSteps + (rn % kChunkSteps)) * RD;
+    a_next = absorption(4 * rn + jj);  // rows are padded to 4*(steps+1) entries
+    const double wa = w_cur, ua = u_cur;
+#pragma unroll
+    for (int cc = 0; cc < NTW; ++cc)
+      acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? wa : ua, bop[cc], acc[cc], 0, 0, 0);
+    GPDLA_MPREP(rec, a_next)
+  }
+#undef GPDLA_MPREP
+  __syncthreads();
+  double logd_sum = log(dprod) + (double)dexp * 0.6931471805599453;
+  quad_sum += __shfl_xor(quad_sum, 16);
+  quad_sum += __shfl_xor(quad_sum, 32);
+  logd_sum += __shfl_xor(logd_sum, 16);
+  logd_sum += __shfl_xor(logd_sum, 32);
+
+  constexpr int ncols = NT * 16;
+  double *Eg = stage + (size_t)group * 4 * ncols;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int src_lane = (jj + 4 * r) + 16 * jj;
+    const double q_s = __shfl(quad_sum, src_lane);
+    const double ld_s = __shfl(logd_sum, src_lane);
+    const int64_t slot_s = slot0 + jj + 4 * r;
+    const double ll = factor_round<NTW, TS, TW>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
+                                                q_s, ld_s, m.n_kept);
+    if (role == 0 && s == 0) {
+      if (slot_s < a.S) {
+        if (a.mode == 0) a.sample_ll_lls[q * a.S + slot_s] = ll - a.log_S;                 // multi :376-378
+        else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ll - a.log_S;  // :359-361
+      } else if (slot_s == a.S && a.mode == 1) {
+        a.ll_no_dla[q] = ll;                                                                // multi :296-298
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Block-wide helpers (256 threads).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_multi_evidence: one block per quasar, for model `nd` (and the LLS model when nd == 1).
+// ------------------------------------------------------------------------------------------
+struct MultiEvidenceArgs {
+  const QuasarMeta *meta;
+  const double *offset_samples, *log_nhi_samples;
+  const uint32_t *base_inds;
+  int32_t *alive;
+  int64_t S;
+  int32_t nd, max_dlas;
+  double min_z_separation, log_S;
+  double *sample_ll_dla, *sample_ll_lls;
+  double *ll_dla;     // [nq][max_dlas]
+  double *ll_lls;     // [nq]
+  double *map_z, *map_lognhi, *map_ind;   // [nq][max_dlas][max_dlas]
+};
+
+__device__ inline void nan_evidence(const double *ll, int64_t S, double *sh, double *out_max,
+                                    double *out_lme, int64_t *out_arg) {
+  // nanmax with the FIRST index attaining it, then max + log(nanmean(exp(ll - max)))  (multi :400-408)
+  const int tid = threadIdx.x;
+  double mx = -INFINITY;
+  int64_t arg = S;
+  for (int64_t i = tid; i < S; i += 256) {
+    const double v = ll[i];
+    if (!isnan(v) && (v > mx || (v == mx && i < arg))) {
+      mx = v;
+      arg = i;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double om = __shfl_xor(mx, o);
+    const long long oa = __shfl_xor((long long)arg, o);
+    if (om > mx || (om == mx && oa < arg)) {
+      mx = om;
+      arg = oa;
+    }
+  }
+  __shared__ double s_m[4];
+  __shared__ long long s_a[4];
+  const int wave = tid >> 6, lane = tid & 63;
+  __syncthreads();
+  if (lane == 0) {
+    s_m[wave] = mx;
+    s_a[wave] = arg;
+  }
+  __syncthreads();
+  mx = s_m[0];
+  arg = s_a[0];
+  for (int w = 1; w < 4; ++w)
+    if (s_m[w] > mx || (s_m[w] == mx && s_a[w] < arg)) {
+      mx = s_m[w];
+      arg = s_a[w];
+    }
+  const bool any = arg < S;
+  double sum = 0.0, cnt = 0.0;
+  for (int64_t i = tid; i < S; i += 256) {
+    const double v = ll[i];
+    if (!isnan(v)) {
+      sum += exp(v - mx);
+      cnt += 1.0;
+    }
+  }
+  sum = block_sum(sum, sh);
+  cnt = block_sum(cnt, sh);
+  *out_max = any ? mx : NAN;
+  *out_lme = any ? mx + log(sum / cnt) : NAN;
+  *out_arg = any ? arg : 0;  // MATLAB's nanmax of an all-NaN column returns index 1
+}
+
+__global__ __launch_bounds__(256) void k_multi_evidence(MultiEvidenceArgs a) {
+  const int q = blockIdx.x, tid = threadIdx.x;
+  __shared__ double sh[4];
+  const QuasarMeta m = a.meta[q];
+  if (m.status != 0 || a.alive[q] == 0) return;
+  const int nd = a.nd, md = a.max_dlas;
+  double *col = a.sample_ll_dla + ((int64_t)q * md + (nd - 1)) * a.S;
+  const uint32_t *base = a.base_inds + (int64_t)q * (md - 1) * a.S;
+  const double zr = m.max_z_dla - m.min_z_dla;
+  if (nd > 1) {  // multi :386-392: any two absorbers of the sample closer than min_z_separation
+    for (int64_t i = tid; i < a.S; i += 256) {
+      double zs[4];
+      zs[0] = m.min_z_dla + zr * a.offset_samples[i];
+      for (int j = 1; j < nd; ++j) zs[j] = m.min_z_dla + zr * a.offset_samples[base[(int64_t)(j - 1) * a.S + i] - 1];
+      bool close = false;
+      for (int x = 0; x < nd; ++x)
+        for (int y = x + 1; y < nd; ++y) close |= fabs(zs[x] - zs[y]) < a.min_z_separation;
+      if (close) col[i] = NAN;
+    }
+    __syncthreads();
+  }
+  double mx, lme;
+  int64_t arg;
+  nan_evidence(col, a.S, sh, &mx, &lme, &arg);
+  if (tid == 0) {
+    const double ev = lme - a.log_S * (nd - 1);  // multi :407-409
+    a.ll_dla[(int64_t)q * md + (nd - 1)] = ev;
+    // MAP bookkeeping, multi :439-445 ([model][slot], 1-based indices)
+    for (int j = 0; j < nd; ++j) {
+      const int64_t idx = j == 0 ? arg : (int64_t)base[(int64_t)(j - 1) * a.S + arg] - 1;
+      const int64_t at = ((int64_t)q * md + (nd - 1)) * md + j;
+      a.map_ind[at] = (double)(idx + 1);
+      a.map_z[at] = m.min_z_dla + zr * a.offset_samples[idx];
+      a.map_lognhi[at] = a.log_nhi_samples[idx];
+    }
+    if (isnan(ev)) a.alive[q] = 0;  // multi :460-464
+  }
+  if (nd == 1) {  // multi :416-430
+    double mx2, lme2;
+    int64_t arg2;
+    nan_evidence(a.sample_ll_lls + (int64_t)q * a.S, a.S, sh, &mx2, &lme2, &arg2);
+    if (tid == 0) a.ll_lls[q] = lme2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_multi_resample: base_sample_inds(nd, :) ~ randsample(S, S, true, W), W = exp(ll - max) with
+// NaN -> 0 (multi :467-472).  MATLAB's generator cannot be reproduced; this one is Philox4x32-10
+// keyed by (seed, global quasar index) with counter (draw j, model nd), inverse-CDF sampling on the
+// prefix sums of W taken in sample order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t *out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct MultiResampleArgs {
+  const QuasarMeta *meta;
+  const int32_t *alive;
+  const double *sample_ll_dla;
+  int64_t S, first_quasar_index;
+  uint64_t seed;
+  int32_t nd, max_dlas;
+  uint32_t *base_inds;
+};
+
+__global__ __launch_bounds__(256) void k_multi_resample(MultiResampleArgs a) {
+  extern __shared__ double cdf[];  // [S]
+  __shared__ double sh[4];
+  __shared__ double s_part[256];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const QuasarMeta m = a.meta[q];
+  if (m.status != 0 || a.alive[q] == 0) return;
+  const double *col = a.sample_ll_dla + ((int64_t)q * a.max_dlas + (a.nd - 1)) * a.S;
+  double mx = -INFINITY;
+  for (int64_t i = tid; i < a.S; i += 256) {
+    const double v = col[i];
+    if (!isnan(v)) mx = fmax(mx, v);
+  }
+  mx = block_reduce_minmax(mx, false, sh);
+  // chunked inclusive scan: thread t owns [t*chunk, (t+1)*chunk)
+  const int64_t chunk = (a.S + 255) / 256;
+  const int64_t lo = (int64_t)tid * chunk, hi = lo + chunk < a.S ? lo + chunk : a.S;
+  double run = 0.0;
+  for (int64_t i = lo; i < hi; ++i) {
+    const double v = col[i];
+    run += isnan(v) ? 0.0 : exp(v - mx);
+    cdf[i] = run;
+  }
+  s_part[tid] = run;
+  __syncthreads();
+  if (tid == 0) {
+    double acc = 0.0;
+    for (int t = 0; t < 256; ++t) {
+      const double v = s_part[t];
+      s_part[t] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  const double off = s_part[tid];
+  for (int64_t i = lo; i < hi; ++i) cdf[i] += off;
+  __syncthreads();
+  const double total = cdf[a.S - 1];
+  const uint64_t qid = (uint64_t)(a.first_quasar_index + q);
+  uint32_t *out = a.base_inds + ((int64_t)q * (a.max_dlas - 1) + (a.nd - 1)) * a.S;
+  for (int64_t j = tid; j < a.S; j += 256) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), (uint32_t)a.nd, 0u,
+                  (uint32_t)(a.seed ^ qid), (uint32_t)((a.seed >> 32) ^ (qid >> 32) ^ 0x5851F42Du), r);
+    const double u = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) * (1.0 / 9007199254740992.0);
+    const double target = u * total;
+    int64_t lo2 = 0, hi2 = a.S - 1;  // first index with cdf > target
+    while (lo2 < hi2) {
+      const int64_t mid = (lo2 + hi2) >> 1;
+      if (cdf[mid] > target) hi2 = mid; else lo2 = mid + 1;
+    }
+    out[j] = (uint32_t)(lo2 + 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_multi_posteriors: multi :300-301, :411-413, :428-430, :482-495.  One thread per quasar.
+// post: [nq][2 + max_dlas] = (no DLA, LLS, 1..max_dlas DLAs).
+// ------------------------------------------------------------------------------------------
+struct MultiPostArgs {
+  const QuasarMeta *meta;
+  int64_t nq;
+  int32_t max_dlas;
+  const double *lp_no, *lp_lls, *lp_dla;   // log priors: [nq], [nq], [nq][max_dlas]
+  const double *ll_no, *ll_lls, *ll_dla;
+  double *lpost_no, *lpost_lls, *lpost_dla, *post, *p_no, *p_lls, *p_dla;
+};
+
+__global__ void k_multi_posteriors(MultiPostArgs a) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.nq) return;
+  const int md = a.max_dlas, nm = 2 + md;
+  double lp[2 + 8];
+  lp[0] = a.lp_no[q] + a.ll_no[q];
+  lp[1] = a.lp_lls[q] + a.ll_lls[q];
+  for (int j = 0; j < md; ++j) lp[2 + j] = a.lp_dla[q * md + j] + a.ll_dla[q * md + j];
+  a.lpost_no[q] = lp[0];
+  a.lpost_lls[q] = lp[1];
+  for (int j = 0; j < md; ++j) a.lpost_dla[q * md + j] = lp[2 + j];
+  double mx = -INFINITY;  // MATLAB max skips NaN (:482-483)
+  bool any = false;
+  for (int j = 0; j < nm; ++j)
+    if (!isnan(lp[j])) {
+      mx = fmax(mx, lp[j]);
+      any = true;
+    }
+  if (!any) mx = NAN;
+  double e[2 + 8], sum = 0.0;
+  for (int j = 0; j < nm; ++j) {
+    e[j] = exp(lp[j] - mx);  // :485-488
+    sum += e[j];             // NaN entries propagate, as sum() does (:491)
+  }
+  for (int j = 0; j < nm; ++j) a.post[q * nm + j] = e[j] * (1.0 / sum);
+  a.p_no[q] = a.post[q * nm];
+  a.p_lls[q] = a.post[q * nm + 1];
+  a.p_dla[q] = 1 - a.p_no[q] - a.p_lls[q];  // :493-495
+}
+
+}  // namespace gpdla

@@ -40,6 +40,7 @@ constexpr double kLog2Pi = 1.83787706640934534;  // log_mvnpdf_low_rank.m:7
 struct LineTable {
   double wavelength_cm[kMaxLines];  // voigt.c:31
   double leading[kMaxLines];        // voigt.c:151
+  double osc[kMaxLines];            // oscillator strengths, voigt.c:66 (multi-DLA mean-flux model)
   double y[kMaxLines];              // gamma_j / (sqrt2 sigma): damping parameter of w(z)
   double y2[kMaxLines];             // y_j^2
   double cwing[kMaxLines];          // leading_j * y_j            (wing formula prefactor)
@@ -93,6 +94,11 @@ struct PrepareArgs {
   PixelRow *pix;           // pool
   double *Mi;              // pool [row][k] interpolated (and zeroed for masked rows) M
   double *lam_pad;         // pool
+  // multi-DLA driver only (process_qsos_multiple_dlas_meanflux.m:245-293): Lyman-series noise
+  // scaling and mean-flux suppression of mu, M, omega2
+  int32_t multi;
+  int32_t num_forest_lines;
+  double prev_tau_0, prev_beta;
 };
 
 __device__ __forceinline__ double block_reduce_minmax(double v, bool is_min, double *sh) {
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
       un_max = fmax(un_max, wl);
       const bool keep = a.pixel_mask[base + i] == 0;                       // :110, :181
       PixelRow row = {0.0, 0.0, 0.0, 1.0};  // masked: contributes r = 0, d = 1, zero B-operand row
+      double mf = 1.0;                       // mean-flux factor applied to mu and M (multi only)
       // bracket rest in the model grid (griddedInterpolant 'linear', :66-71)
       int lo = 0, hi = G - 1;
       if (rest >= a.model.rest[G - 1]) lo = G - 2;
@@ -173,13 +180,41 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
                              (a.model.log_omega[lo + 1] - a.model.log_omega[lo]) * t;  // :141
         const double omega2 = exp(2 * lo_om);                                          // :142
         const double lya_z = (wl - a.cfg.lya_wavelength) / a.cfg.lya_wavelength;       // :117-119
-        const double sc = 1 - exp(-a.model.tau_0 * pow(1 + lya_z, a.model.beta)) + a.model.c_0; // :144
-        row.omega2 = omega2 * (sc * sc);                                               // :146
+        if (!a.multi) {
+          const double sc = 1 - exp(-a.model.tau_0 * pow(1 + lya_z, a.model.beta)) + a.model.c_0; // :144
+          row.omega2 = omega2 * (sc * sc);                                             // :146
+        } else {
+          // multi :245-263: effective optical depth of the whole Lyman series in the noise model
+          const double wl_1 = g_lines.wavelength_cm[0] * 1e8, f_1 = g_lines.osc[0];
+          double depth = a.model.tau_0 * pow(1 + lya_z, a.model.beta);
+          for (int l = 1; l < a.num_forest_lines; ++l) {
+            const double wl_l = g_lines.wavelength_cm[l] * 1e8;
+            double one_pz = wl_1 * (1 + lya_z) / wl_l;                                 // multi :248-249
+            one_pz = one_pz * ((one_pz <= (1 + z_qso)) ? 1.0 : 0.0);                   // multi :252-253
+            const double tau = a.model.tau_0 * wl_l * g_lines.osc[l] / (wl_1 * f_1);   // multi :255-256
+            depth = depth + tau * pow(one_pz, a.model.beta);                           // multi :258
+          }
+          const double sc = 1 - exp(-depth) + a.model.c_0;                             // multi :261
+          double om = omega2 * (sc * sc);                                              // multi :263
+          // multi :267-285: mean-flux suppression exp(-Sum tau_l (1+z_l)^beta) with Kim's priors
+          double total = 0.0;
+          for (int l = 0; l < a.num_forest_lines; ++l) {
+            const double wl_l = g_lines.wavelength_cm[l] * 1e8;
+            const double z_l = (wl - wl_l) / wl_l;                                     // multi :184-186
+            const double tau_l = a.prev_tau_0 * g_lines.osc[l] / f_1 * wl_l / a.cfg.lya_wavelength;
+            const double od = tau_l * pow(1 + z_l, a.prev_beta);                       // multi :275-276
+            if (l > 0 && z_l > z_qso) continue;                                        // multi :279-282
+            total += od;
+          }
+          mf = exp(-total);                                                            // multi :285
+          row.mu = row.mu * mf;                                                        // multi :287
+          row.omega2 = om * (mf * mf);                                                 // multi :293
+        }
       }
       pix[u] = row;
       for (int c = 0; c < k; ++c) {                                                    // :139
         const double m0 = a.model.M[lo + (int64_t)c * G], m1 = a.model.M[lo + 1 + (int64_t)c * G];
-        Mi[(int64_t)u * k + c] = keep ? m0 + (m1 - m0) * t : 0.0;
+        Mi[(int64_t)u * k + c] = keep ? (m0 + (m1 - m0) * t) * mf : 0.0;  // multi :288
       }
     }
     __syncthreads();
@@ -392,6 +427,68 @@ __device__ __forceinline__ void glds16(const double *gsrc, double *lds_wave_base
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void *)gsrc,
       (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// Epilogue shared by the sweep kernels: one round (MFMA result register r) of the per-sample
+// factorisation.  The 16 lanes of row jj hold, in register r of every tile, the 16*NT columns of
+// sample jj + 4r: they spill them to LDS (e = [16*NT] doubles for this row) and factor the augmented
+// (k+1) x (k+1) matrix [[I + B, v], [v', .]] column by column, lane s taking rows j+1+s, j+1+s+16
+// of column j.  Row k of the augmented matrix is v, so its factor row is z = L^-1 v.
+// Returns log N(y; a mu, ...) of that sample (log_mvnpdf_low_rank.m:30-32) in every lane of the row
+// (meaningful for role 0 only).  q_s = Sum r^2/d, ld_s = Sum log d of the sample.
+template <int NTW, int TS, int TW>
+__device__ __forceinline__ double factor_round(const d4 (&acc)[NTW], int r, double *e, int s,
+                                               int role, int tile0, int k, double q_s, double ld_s,
+                                               int n_kept) {
+  constexpr int voff = TW * 16;
+  if (TS > 1) __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < NTW; ++cc) e[(tile0 + cc) * 16 + s] = acc[cc][r];
+  if (TS > 1) __syncthreads();
+  else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  double ll = NAN;
+#ifdef GPDLA_ABLATE_NOEPI
+  ll = q_s + ld_s + e[0];
+  if (false) {
+#else
+  if (role == 0) {
+#endif
+    double lprod = 1.0, zz = 0.0;
+    bool pd = true;
+    for (int j = 0; j < k; ++j) {
+      const int rj = j * (j + 1) / 2;
+      double dj = e[rj + j] + 1.0;  // log_mvnpdf_low_rank.m:22-23
+      for (int mm = 0; mm < j; ++mm) {
+        const double t = e[rj + mm];
+        dj = fma(-t, t, dj);
+      }
+      pd = pd && (dj > 0.0);
+      const double ljj = sqrt(dj);  // :24
+      const double inv = 1.0 / ljj;
+      lprod *= ljj;
+      for (int i = j + 1 + s; i <= k; i += 16) {
+        const int ri = (i < k) ? i * (i + 1) / 2 : voff;
+        double t = e[ri + j];
+        for (int mm = 0; mm < j; ++mm) t = fma(-e[ri + mm], e[rj + mm], t);
+        t *= inv;
+        e[ri + j] = t;
+        if (i == k) zz = fma(t, t, zz);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    zz += __shfl_xor(zz, 1);
+    zz += __shfl_xor(zz, 2);
+    zz += __shfl_xor(zz, 4);
+    zz += __shfl_xor(zz, 8);
+    const double log_det = ld_s + 2 * log(lprod);  // :30
+    ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);  // :32
+    if (!pd) ll = NAN;
+  }
+  return ll;
 }
 
 // Sum over the Lyman lines of lead_j * Re w_j * sqrt(pi) at one padded pixel (voigt.c:285-289).
@@ -784,78 +881,22 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   logd_sum += __shfl_xor(logd_sum, 32);
 
 #undef GPDLA_RAW_ACCURATE
-  // ---- epilogue: (k+1) x (k+1) column Cholesky of [[I + B, v], [v', .]] per sample -----------
-  // Four rounds (MFMA result register r = 0..3).  In round r the 16 lanes of row jj hold, in
-  // register r of every tile, the 16*NT columns of sample jj + 4r: they spill them to LDS and
-  // factor that sample together, lane s taking rows j+1+s, j+1+s+16 of each column j.  Row k of
-  // the augmented matrix is v, so its factor row is z = L^-1 v.
+  // ---- epilogue: four rounds of factor_round (MFMA result register r = 0..3) ----------------
   constexpr int ncols = NT * 16;
-  const int k = a.k;
-  constexpr int voff = TW * 16;
   double *Eg = stage + (size_t)group * 4 * ncols;  // [4 samples][ncols] for this sample group
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (TS > 1) __syncthreads();
-    double *e = Eg + (size_t)jj * ncols;
-#pragma unroll
-    for (int cc = 0; cc < NTW; ++cc) e[(tile0 + cc) * 16 + s] = acc[cc][r];
-    if (TS > 1) __syncthreads();
-    else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
     // scalars of sample jj + 4r live in the lanes whose s equals jj + 4r
     const int src_lane = (jj + 4 * r) + 16 * jj;
     const double q_s = __shfl(quad_sum, src_lane);
     const double ld_s = __shfl(logd_sum, src_lane);
     const int64_t slot_s = slot0 + jj + 4 * r;
     const int32_t sample_s = __shfl(sample, src_lane);
-#ifdef GPDLA_ABLATE_NOEPI
+    const double ll = factor_round<NTW, TS, TW>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
+                                                q_s, ld_s, m.n_kept);
     if (role == 0 && s == 0) {
-      const double ll = q_s + ld_s + e[0];
       if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
       else if (slot_s == a.S) a.ll_no_dla[q] = ll;
-    }
-    if (false) {
-#else
-    if (role == 0) {
-#endif
-      double lprod = 1.0, zz = 0.0;
-      bool pd = true;
-      for (int j = 0; j < k; ++j) {
-        const int rj = j * (j + 1) / 2;
-        double dj = e[rj + j] + 1.0;  // log_mvnpdf_low_rank.m:22-23
-        for (int mm = 0; mm < j; ++mm) {
-          const double t = e[rj + mm];
-          dj = fma(-t, t, dj);
-        }
-        pd = pd && (dj > 0.0);
-        const double ljj = sqrt(dj);  // :24
-        const double inv = 1.0 / ljj;
-        lprod *= ljj;
-        for (int i = j + 1 + s; i <= k; i += 16) {
-          const int ri = (i < k) ? i * (i + 1) / 2 : voff;
-          double t = e[ri + j];
-          for (int mm = 0; mm < j; ++mm) t = fma(-e[ri + mm], e[rj + mm], t);
-          t *= inv;
-          e[ri + j] = t;
-          if (i == k) zz = fma(t, t, zz);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-      zz += __shfl_xor(zz, 1);
-      zz += __shfl_xor(zz, 2);
-      zz += __shfl_xor(zz, 4);
-      zz += __shfl_xor(zz, 8);
-      if (s == 0) {
-        // log_mvnpdf_low_rank.m:30-32
-        const double log_det = ld_s + 2 * log(lprod);
-        double ll = -0.5 * ((q_s - zz) + log_det + (double)m.n_kept * kLog2Pi);
-        if (!pd) ll = NAN;
-        if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
-        else if (slot_s == a.S) a.ll_no_dla[q] = ll;
-      }
     }
   }
 }

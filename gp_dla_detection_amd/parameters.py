@@ -51,3 +51,5 @@ class MultiParameters(Parameters):
     prev_tau_0: float = 0.0023                 # :36
     prev_beta: float = 3.65                    # :37
     num_forest_lines: int = 31                 # set_parameters_multi.m:75
+    rng_seed: int = 0x9E3779B97F4A7C15         # GPU resampling stream (the reference: rng('default'))
+    first_quasar_index: int = 0                # global index of this batch's first quasar (sharding)

@@ -95,7 +95,7 @@ typedef struct {
   const uint8_t *pixel_mask;        /* nonzero = masked */
   const double *z_qsos;             /* [num_quasars] */
   const double *log_priors_no_dla;  /* [num_quasars]  process_qsos.m:130-131 (host logic) */
-  const double *log_priors_dla;     /* [num_quasars]  process_qsos.m:128-129; multi: [nq x max_dlas] col-major */
+  const double *log_priors_dla;     /* [num_quasars]  process_qsos.m:128-129; multi: [nq][max_dlas] (multi :204) */
   const double *log_priors_lls;     /* multi only (:208-210), else NULL */
 } gpdla_spectra;
 
@@ -113,6 +113,11 @@ typedef struct {
   int32_t num_forest_lines;
   double min_z_separation;
   double prev_tau_0, prev_beta;
+  /* weighted resampling of the multi-DLA driver when base_sample_inds is not supplied: the draw
+   * for (quasar, model, index) depends only on rng_seed and first_quasar_index + local quasar
+   * index, so shards of one run pass their global offset here and agree with an unsharded run */
+  uint64_t rng_seed;
+  int64_t first_quasar_index;
 } gpdla_config;
 
 /* Fills a gpdla_config with the reference's defaults (set_parameters.m / set_parameters_multi.m). */
@@ -190,8 +195,11 @@ int gpdla_context_set_timing(gpdla_context *ctx, int enabled);
 /* ---------------------------------------------------------------------------------------------
  * Multi-DLA driver: multi_dlas/process_qsos_multiple_dlas_meanflux.m.
  * base_sample_inds: [nq][max_dlas-1][S] uint32, 1-BASED as in the reference's output file (:116,
- * :476); it is an INPUT here because MATLAB's rng('default') + randsample stream (:143, :471-472)
- * cannot be reproduced outside MATLAB.
+ * :476).  MATLAB's rng('default') + randsample stream (:143, :471-472) cannot be reproduced outside
+ * MATLAB, so either the caller supplies the indices (replaying a
+ * reference output, or for parity tests), or passes NULL and they are drawn on the GPU with a
+ * documented counter-based generator (Philox4x32-10, inverse-CDF sampling; config->rng_seed).
+ * Either way the indices used are returned in results->base_sample_inds.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   double *min_z_dlas, *max_z_dlas;        /* [nq] */
@@ -206,6 +214,7 @@ typedef struct {
   double *model_posteriors;               /* [nq][2 + max_dlas] = (no DLA, LLS, 1..max_dlas DLAs) */
   double *p_no_dlas, *p_lls, *p_dlas;     /* [nq] */
   double *MAP_z_dlas, *MAP_log_nhis, *MAP_inds; /* [nq][max_dlas(model)][max_dlas(slot)], NaN unused */
+  uint32_t *base_sample_inds;             /* [nq][max_dlas-1][S], 1-based: the indices used (:476) */
   int32_t *status;                        /* [nq] 1 = all_exceptions (:232) */
 } gpdla_results_multi;
 
