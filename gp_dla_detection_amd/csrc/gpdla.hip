@@ -425,7 +425,7 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   const size_t stage_doubles = 2 * (size_t)CH * RD;
   const size_t epi_doubles = (size_t)groups * 4 * b->ntiles * 16;
   if (epi_doubles > stage_doubles) return fail(GPDLA_ERR_UNSUPPORTED, "epilogue does not fit the stage buffers");
-  const size_t lds = (stage_doubles + (size_t)kSweepWaves * kSamplesPerWave * kRingStride +
+  const size_t lds = (stage_doubles + (size_t)kSweepWaves * kSamplesPerWave * kRing2 + kExpTab +
                       (size_t)groups * kSamplesPerWave * L) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "sweep needs %zu B of LDS", lds);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<NTW, TS, CH, TW, LINES>),

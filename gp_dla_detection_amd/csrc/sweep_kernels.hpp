@@ -436,7 +436,55 @@ __device__ __forceinline__ void glds16(const double *gsrc, double *lds_wave_base
 // of column j.  Row k of the augmented matrix is v, so its factor row is z = L^-1 v.
 // Returns log N(y; a mu, ...) of that sample (log_mvnpdf_low_rank.m:30-32) in every lane of the row
 // (meaningful for role 0 only).  q_s = Sum r^2/d, ld_s = Sum log d of the sample.
-template <int NTW, int TS, int TW>
+// One column of the factorisation: diagonal, then this lane's rows below it.
+__device__ __forceinline__ void factor_column(double *e, int j, int k, int s, int voff,
+                                              double &lprod, double &zz, bool &pd) {
+  const int rj = j * (j + 1) / 2;
+  double dj = e[rj + j] + 1.0;  // log_mvnpdf_low_rank.m:22-23
+  for (int mm = 0; mm < j; ++mm) {
+    const double t = e[rj + mm];
+    dj = fma(-t, t, dj);
+  }
+  pd = pd && (dj > 0.0);
+  const double ljj = sqrt(dj);  // :24
+  const double inv = 1.0 / ljj;
+  lprod *= ljj;
+  for (int i = j + 1 + s; i <= k; i += 16) {
+    const int ri = (i < k) ? i * (i + 1) / 2 : voff;
+    double t = e[ri + j];
+    for (int mm = 0; mm < j; ++mm) t = fma(-e[ri + mm], e[rj + mm], t);
+    t *= inv;
+    e[ri + j] = t;
+    if (i == k) zz = fma(t, t, zz);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The factorisation proper, on one sample's columns already in LDS.
+// KC: k when known at compile time (the column loop is then fully unrolled, which lets the
+// compiler batch the LDS reads of each dot product), 0 for a run-time k.
+template <int KC>
+__device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, double q_s, double ld_s,
+                                          int n_kept) {
+  double lprod = 1.0, zz = 0.0;
+  bool pd = true;
+  if (KC > 0) {
+#pragma unroll
+    for (int j = 0; j < KC; ++j) factor_column(e, j, KC, s, voff, lprod, zz, pd);
+  } else {
+    for (int j = 0; j < k; ++j) factor_column(e, j, k, s, voff, lprod, zz, pd);
+  }
+  zz += __shfl_xor(zz, 1);
+  zz += __shfl_xor(zz, 2);
+  zz += __shfl_xor(zz, 4);
+  zz += __shfl_xor(zz, 8);
+  const double log_det = ld_s + 2 * log(lprod);  // log_mvnpdf_low_rank.m:30
+  const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);  // :32
+  return pd ? ll : NAN;
+}
+
+template <int NTW, int TS, int TW, int KC>
 __device__ __forceinline__ double factor_round(const d4 (&acc)[NTW], int r, double *e, int s,
                                                int role, int tile0, int k, double q_s, double ld_s,
                                                int n_kept) {
@@ -449,46 +497,11 @@ __device__ __forceinline__ double factor_round(const d4 (&acc)[NTW], int r, doub
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  double ll = NAN;
 #ifdef GPDLA_ABLATE_NOEPI
-  ll = q_s + ld_s + e[0];
-  if (false) {
+  return q_s + ld_s + e[0];
 #else
-  if (role == 0) {
+  return role == 0 ? factor_lds<KC>(e, s, k, voff, q_s, ld_s, n_kept) : NAN;
 #endif
-    double lprod = 1.0, zz = 0.0;
-    bool pd = true;
-    for (int j = 0; j < k; ++j) {
-      const int rj = j * (j + 1) / 2;
-      double dj = e[rj + j] + 1.0;  // log_mvnpdf_low_rank.m:22-23
-      for (int mm = 0; mm < j; ++mm) {
-        const double t = e[rj + mm];
-        dj = fma(-t, t, dj);
-      }
-      pd = pd && (dj > 0.0);
-      const double ljj = sqrt(dj);  // :24
-      const double inv = 1.0 / ljj;
-      lprod *= ljj;
-      for (int i = j + 1 + s; i <= k; i += 16) {
-        const int ri = (i < k) ? i * (i + 1) / 2 : voff;
-        double t = e[ri + j];
-        for (int mm = 0; mm < j; ++mm) t = fma(-e[ri + mm], e[rj + mm], t);
-        t *= inv;
-        e[ri + j] = t;
-        if (i == k) zz = fma(t, t, zz);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    zz += __shfl_xor(zz, 1);
-    zz += __shfl_xor(zz, 2);
-    zz += __shfl_xor(zz, 4);
-    zz += __shfl_xor(zz, 8);
-    const double log_det = ld_s + 2 * log(lprod);  // :30
-    ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);  // :32
-    if (!pd) ll = NAN;
-  }
-  return ll;
 }
 
 // Sum over the Lyman lines of lead_j * Re w_j * sqrt(pi) at one padded pixel (voigt.c:285-289).
@@ -564,9 +577,34 @@ __device__ __noinline__ double raw_accurate(double lamP, double m0, double m1, d
 // Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk,
 // TW tiles that take the weight w (the rest take u; TS*NTW tiles in all, zero-padded), LINES
 // number of Lyman lines when known at compile time (0: read num_lines at run time).
+constexpr int kRing2 = 33;   // doubled raw-profile ring: 32 slots + 1 pad per sample
+constexpr int kExpTab = 64;  // entries of the 2^(j/64) table behind exp_table()
+
+// exp(x) for x <= 0 through a 64-entry table: x = (64 n + j) ln2/64 + r, |r| <= ln2/128,
+// exp(x) = 2^n * 2^(j/64) * P5(r).  Relative error < 2e-16 (r^6/720 < 3.6e-17).
+__device__ __forceinline__ double exp_table(double x, const double *tab) {
+  x = fmax(x, -800.0);
+  const double nf = rint(x * 92.33248261689366);            // 64 / ln2
+  double r = fma(-nf, 0.010830424667801708, x);               // ln2/64 high part (low 24 bits zero)
+  r = fma(-nf, 2.8447437476627285e-11, r);                    // ln2/64 low part
+  const int ni = (int)nf;
+  double p = 0.008333333333333333;
+  p = fma(p, r, 0.041666666666666664);
+  p = fma(p, r, 0.16666666666666666);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(tab[ni & (kExpTab - 1)] * p, ni >> 6);
+}
+
+// Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk
+// (must be 4: the step loop is unrolled over the chunk so ring slots are compile-time),
+// TW tiles that take the weight w (the rest take u; TS*NTW tiles in all, zero-padded), LINES
+// number of Lyman lines when known at compile time (0: read num_lines at run time).
 template <int NTW, int TS, int kChunkSteps, int TW, int LINES>
 __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   extern __shared__ double smem[];
+  static_assert(kChunkSteps == 4 || kChunkSteps == 1, "step loop is written for chunks of 4 (or 1)");
   constexpr int GROUPS = kSweepWaves / TS;  // sample groups per block
   constexpr int NT = NTW * TS;
   constexpr int RD = NT * 64 + 32;
@@ -582,8 +620,9 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   const int L = LINES > 0 ? LINES : a.num_lines;
 
   double *stage = smem;                                            // [2][kChunkSteps][RD]
-  double *ring = stage + (size_t)2 * kChunkSteps * RD;             // [8 waves][16][17]
-  double *mult_s = ring + kSweepWaves * kSamplesPerWave * kRingStride;  // [GROUPS*16][L]
+  double *ring = stage + (size_t)2 * kChunkSteps * RD;             // [8 waves][16][33]
+  double *exp_tab = ring + kSweepWaves * kSamplesPerWave * kRing2; // [64]
+  double *mult_s = exp_tab + kExpTab;                              // [GROUPS*16][L]
 
   const int64_t slot0 = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave;
   const int64_t slot = slot0 + s;
@@ -602,19 +641,19 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   } else if (role == 0 && jj == 0) {
     for (int j = 0; j < L; ++j) my_mult[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
   }
-  double *my_ring = ring + (size_t)(wave * kSamplesPerWave + s) * kRingStride;
+  if (tid < kExpTab) exp_tab[tid] = exp2((double)tid * (1.0 / kExpTab));
+  // this lane's ring row, already offset by its pixel phase jj (slots are then compile-time)
+  double *my_ring = ring + (size_t)(wave * kSamplesPerWave + s) * kRing2 + jj;
   const double *lam = a.lam_pad + m.lam_off;
   const int n_pad = m.n_u + 6;
   // exp(N * total / (sqrt(2 pi) sigma)) with total = -Sum lead_j Re w_j (voigt.c:288-291)
   const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
   const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
+  const int nchunks = (m.steps + kChunkSteps - 1) / kChunkSteps;
 
-  // asynchronous global -> LDS copy of one chunk of records (1 KiB per wave-instruction).
-  // A quasar has steps + 1 records; the last one is neutral (zero tiles, d = 1).
-  const int nrec = m.steps + 1;
-  const int nchunks = (nrec + kChunkSteps - 1) / kChunkSteps;
+  // asynchronous global -> LDS copy of one chunk of records (1 KiB per wave-instruction)
   auto issue_chunk = [&](int c) {
-    const int csteps = min(kChunkSteps, nrec - c * kChunkSteps);
+    const int csteps = min(kChunkSteps, m.steps - c * kChunkSteps);
     const int units = csteps * (RD / 2);  // 16-byte units
     const double *src = rec_base + (size_t)c * kChunkSteps * RD;
     double *dst = stage + (size_t)(c & 1) * kChunkSteps * RD;
@@ -625,26 +664,26 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   };
   issue_chunk(0);
 
-  // per-line constants in registers (LINES > 0)
-  double ly[LINES > 0 ? LINES : 1], ly2[LINES > 0 ? LINES : 1], llead[LINES > 0 ? LINES : 1];
-#pragma unroll
-  for (int j = 0; j < (LINES > 0 ? LINES : 0); ++j) {
-    ly[j] = g_lines.y[j];
-    ly2[j] = g_lines.y2[j];
-    llead[j] = g_lines.leading[j];
-  }
   const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
-  const double *mult_p = LINES > 0 ? mult_r : my_mult;
-  // raw (un-broadened) profile exp(-tau) at a padded pixel, accurate tier: voigt.c:282-292
+  // wing tier in FMA form: x = lam * (mult_j / (sqrt2 sigma)) - c / (sqrt2 sigma).  It differs
+  // from the reference's two-rounding velocity (voigt.c:287, kept in the accurate tier) by
+  // <= 3e-12 in x, i.e. <= 2e-13 relative in the optical depth where |x| >= 30.
+  double ms_r[LINES > 0 ? LINES : 1];
+#pragma unroll
+  for (int j = 0; j < (LINES > 0 ? LINES : 0); ++j) ms_r[j] = mult_r[j] * inv_s;
+  const double cs = c_light * inv_s;
 #define GPDLA_RAW_ACCURATE(lamP)                                                            \
   raw_accurate<LINES>((lamP), mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], \
                       my_mult, L, nscale)
 
-  __syncthreads();  // multipliers visible
+  __syncthreads();  // multipliers and the exp table visible
   // prime the ring with padded pixels 0..11 (the raw profile runs three K-steps ahead)
-  my_ring[jj] = GPDLA_RAW_ACCURATE(lam[min(jj, n_pad - 1)]);
-  my_ring[4 + jj] = GPDLA_RAW_ACCURATE(lam[min(4 + jj, n_pad - 1)]);
-  my_ring[8 + jj] = GPDLA_RAW_ACCURATE(lam[min(8 + jj, n_pad - 1)]);
+#pragma unroll
+  for (int c3 = 0; c3 < 3; ++c3) {
+    const double v = GPDLA_RAW_ACCURATE(lam[min(4 * c3 + jj, n_pad - 1)]);
+    my_ring[4 * c3] = v;
+    my_ring[4 * c3 + 16] = v;
+  }
 
   d4 acc[NTW];
 #pragma unroll
@@ -658,221 +697,111 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
 
   __builtin_amdgcn_s_waitcnt(0);  // chunk 0 landed (vmcnt(0))
   __syncthreads();
-  if (nchunks > 1) issue_chunk(1);
 
-  // Software pipeline.  prep(record r) produces everything step r's MFMAs need -- weights (w, u)
-  // and the 16 B-operand fragments -- plus the raw profile three steps ahead.  Iteration t issues
-  // the MFMAs of step t next to prep(record t+1); the two are independent, so the matrix pipe and
-  // the VALU run concurrently inside one wave.  The accurate Faddeeva tier (rare) is a fix-up at
-  // the top of the NEXT iteration (the ring entry it corrects is first read there), which keeps
-  // MFMAs + prep one straight-line block for the scheduler.
-  double w_cur, u_cur, bop[NTW];
-  bool near_c = false;   // carried to the next iteration: this lane's newest ring entry needs
-  double lam_c = 0.0;    // the accurate tier (wavelength lam_c, ring slot slot_c)
-  int slot_c = 0;
-#define GPDLA_PREP(rec, r_index)                                                                  \
-  const double *extra_ = (rec) + NT * 64;                                                         \
-  const double lamP_ = extra_[16 + jj];                                                           \
-  bool near_;                                                                                     \
-  double raw_ = exp_nonpos(nscale * line_sum<LINES, false>(lamP_, mult_p, L, c_light, inv_s, ly,  \
-                                                             ly2, llead, &near_));                \
-  const int p_ = 4 * (r_index) + jj;                                                              \
-  double absorb_ = my_ring[p_ & 15] * tap0;                                                       \
-  absorb_ = fma(my_ring[(p_ + 1) & 15], tap1, absorb_);                                           \
-  absorb_ = fma(my_ring[(p_ + 2) & 15], tap2, absorb_);                                           \
-  absorb_ = fma(my_ring[(p_ + 3) & 15], tap3, absorb_);                                           \
-  absorb_ = fma(my_ring[(p_ + 4) & 15], tap2, absorb_);                                           \
-  absorb_ = fma(my_ring[(p_ + 5) & 15], tap1, absorb_);                                           \
-  absorb_ = fma(my_ring[(p_ + 6) & 15], tap0, absorb_);                                           \
-  if (is_null) absorb_ = 1.0;                                                                     \
-  const double py_ = extra_[4 * jj], pmu_ = extra_[4 * jj + 1], pom_ = extra_[4 * jj + 2],        \
-               pnu_ = extra_[4 * jj + 3];                                                         \
-  const double r_ = fma(-absorb_, pmu_, py_);                                                     \
-  const double a2_ = absorb_ * absorb_;                                                           \
-  const double d_ = fma(pom_, a2_, pnu_);                                                         \
-  const double inv_d_ = fast_rcp(d_);                                                             \
-  w_cur = a2_ * inv_d_;                                                                           \
-  u_cur = absorb_ * r_ * inv_d_;                                                                  \
-  quad_sum = fma(r_ * r_, inv_d_, quad_sum);                                                      \
-  dprod *= d_; /* Sum log d as the log of a running product, renormalised every step */           \
-  dexp += __builtin_amdgcn_frexp_exp(dprod);                                                      \
-  dprod = __builtin_amdgcn_frexp_mant(dprod);                                                     \
-  {                                                                                               \
-    const double *bt_ = (rec) + (size_t)tile0 * 64 + lane;                                        \
-    _Pragma("unroll") for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt_[(size_t)cc * 64];            \
-  }                                                                                               \
-  near_c = near_;                                                                                 \
-  lam_c = lamP_;                                                                                  \
-  slot_c = (p_ + 12) & 15;                                                                        \
-  my_ring[slot_c] = raw_;
-
-  {
-    GPDLA_PREP(stage, 0)
-  }
-  for (int t = 0; t < m.steps; ++t) {
-    const int rn = t + 1;  // record prepared in this iteration
-    const int cn = rn / kChunkSteps;
-    if (rn % kChunkSteps == 0) {   // entering a new chunk: it must have landed in LDS
-      __syncthreads();             // (emits s_waitcnt vmcnt(0) first); chunk cn-1 is now free
-      if (cn + 1 < nchunks) issue_chunk(cn + 1);
-    }
-    const double *rec = stage + ((size_t)(cn & 1) * kChunkSteps + (rn % kChunkSteps)) * RD;
-    // fix-up of the ring entries written by the previous prep with the wing formula although
-    // some lane sat within 30 Doppler widths of a line centre (first read by the conv below)
-#ifndef GPDLA_ABLATE_NOSLOW
-    if (__builtin_expect(__any(near_c), 0)) my_ring[slot_c] = GPDLA_RAW_ACCURATE(lam_c);
-#endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const double wa = w_cur, ua = u_cur;
-    if constexpr (LINES == 3) {
-      // ---- hand-staged block: MFMA cc of step t, then ~10 VALU of prep(record t+1) in its
-      // 64-cycle shadow; sched_barrier(0) pins the interleave (the compiler otherwise issues the
-      // 16 MFMAs back to back and the matrix pipe idles during the VALU work).
-#ifdef GPDLA_ABLATE_NOMFMA
-#define MF(cc)                                                                               \
-  if constexpr ((cc) < NTW) {                                                                \
-    asm volatile("" ::"v"(bop[cc]));                                                         \
-    if ((cc) < 2) acc[cc][0] += ((cc) < nw ? wa : ua) * bop[cc];                             \
-  }
-#else
-#define MF(cc)                                                                               \
-  if constexpr ((cc) < NTW)                                                                  \
-    acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64((cc) < nw ? wa : ua, bop[cc], acc[cc], 0, 0, 0);
-#endif
-#define BREAD(cc)                                                                            \
-  if constexpr ((cc) < NTW) bop[cc] = bt_[(size_t)(cc) * 64];
-#define SB __builtin_amdgcn_sched_barrier(0)
-      const double *extra_ = rec + NT * 64;
-      const double *bt_ = rec + (size_t)tile0 * 64 + lane;
-      const int p_ = 4 * rn + jj;
-      const double lamP_ = extra_[16 + jj];
-      SB;
-      MF(0)  // S0: velocities -> x^2 + y^2 per line (voigt.c:287), reciprocal seeds
-      const double xa = (lamP_ * mult_r[0] - c_light) * inv_s, xb = (lamP_ * mult_r[1] - c_light) * inv_s,
-                   xc = (lamP_ * mult_r[2] - c_light) * inv_s;
-      const double x2a = xa * xa, x2b = xb * xb, x2c = xc * xc;
-      const double sa = x2a + ly2[0], sb = x2b + ly2[1], sc = x2c + ly2[2];
-      double ra = __builtin_amdgcn_rcp(sa), rb = __builtin_amdgcn_rcp(sb), rc = __builtin_amdgcn_rcp(sc);
-      const bool near_ = (x2a < 900.0) | (x2b < 900.0) | (x2c < 900.0);  // accurate tier needed
-      SB;
-      MF(1)  // S1: two Newton steps per reciprocal
-      BREAD(0) BREAD(1)
-      double ea = fma(-sa, ra, 1.0), eb = fma(-sb, rb, 1.0), ec = fma(-sc, rc, 1.0);
-      ra = fma(ra, ea, ra); rb = fma(rb, eb, rb); rc = fma(rc, ec, rc);
-      ea = fma(-sa, ra, 1.0); eb = fma(-sb, rb, 1.0); ec = fma(-sc, rc, 1.0);
-      ra = fma(ra, ea, ra); rb = fma(rb, eb, rb); rc = fma(rc, ec, rc);
-      SB;
-      MF(2)  // S2: wing series T(rho), upper half
-      double ta = fma(kT6, ra, kT5), tb = fma(kT6, rb, kT5), tc = fma(kT6, rc, kT5);
-      ta = fma(ta, ra, kT4); tb = fma(tb, rb, kT4); tc = fma(tc, rc, kT4);
-      ta = fma(ta, ra, kT3); tb = fma(tb, rb, kT3); tc = fma(tc, rc, kT3);
-      SB;
-      MF(3)  // S3: lower half
-      BREAD(2) BREAD(3)
-      ta = fma(ta, ra, kT2); tb = fma(tb, rb, kT2); tc = fma(tc, rc, kT2);
-      ta = fma(ta, ra, kT1); tb = fma(tb, rb, kT1); tc = fma(tc, rc, kT1);
-      ta = fma(ta, ra, kT0); tb = fma(tb, rb, kT0); tc = fma(tc, rc, kT0);
-      SB;
-      MF(4)  // S4: - 2 y^2 rho^2 correction, times rho
-      ta = fma(g_lines.m2y2[0] * ra, ra, ta); tb = fma(g_lines.m2y2[1] * rb, rb, tb);
-      tc = fma(g_lines.m2y2[2] * rc, rc, tc);
-      const double va = ra * ta, vb = rb * tb, vc = rc * tc;
-      SB;
-      MF(5)  // S5: optical depth, exp range reduction
-      BREAD(4) BREAD(5)
-      double ex = nscale * fma(g_lines.cwing[2], vc, fma(g_lines.cwing[1], vb, g_lines.cwing[0] * va));
-      ex = fmax(ex, -800.0);
-      const double en = rint(ex * 1.4426950408889634);
-      double er = fma(-en, 0.6931471803691238, ex);
-      er = fma(-en, 1.9082149292705877e-10, er);
-      SB;
-      MF(6)  // S6: exp Taylor polynomial, degree 12, upper half; ring taps for S8 requested
-      const double g0 = my_ring[p_ & 15], g1 = my_ring[(p_ + 1) & 15], g2 = my_ring[(p_ + 2) & 15],
-                   g3 = my_ring[(p_ + 3) & 15], g4 = my_ring[(p_ + 4) & 15],
-                   g5 = my_ring[(p_ + 5) & 15], g6 = my_ring[(p_ + 6) & 15];
-      double ep = 2.08767569878681e-09;
-      ep = fma(ep, er, 2.505210838544172e-08);
-      ep = fma(ep, er, 2.755731922398589e-07);
-      ep = fma(ep, er, 2.755731922398589e-06);
-      ep = fma(ep, er, 2.48015873015873e-05);
-      ep = fma(ep, er, 0.0001984126984126984);
-      ep = fma(ep, er, 0.001388888888888889);
-      SB;
-      MF(7)  // S7: lower half, scale by 2^n -> raw profile three steps ahead (voigt.c:291)
-      BREAD(6) BREAD(7)
-      const double py_ = extra_[4 * jj], pmu_ = extra_[4 * jj + 1], pom_ = extra_[4 * jj + 2],
-                   pnu_ = extra_[4 * jj + 3];
-      ep = fma(ep, er, 0.008333333333333333);
-      ep = fma(ep, er, 0.041666666666666664);
-      ep = fma(ep, er, 0.16666666666666666);
-      ep = fma(ep, er, 0.5);
-      ep = fma(ep, er, 1.0);
-      ep = fma(ep, er, 1.0);
-#ifdef GPDLA_ABLATE_NOVOIGT
-      const double raw_ = lamP_ * 1e-4;
-#else
-      const double raw_ = ldexp(ep, (int)en);
-#endif
-      SB;
-      MF(8)  // S8: instrument broadening of pixel 4 rn + jj (voigt.c:297-299, symmetric taps)
-      double absorb_ = fma(g6, tap0, g0 * tap0);
-      double ab2 = fma(g5, tap1, g1 * tap1);
-      absorb_ = fma(g2, tap2, absorb_);
-      ab2 = fma(g4, tap2, ab2);
-      absorb_ = fma(g3, tap3, absorb_);
-      absorb_ += ab2;
-      if (is_null) absorb_ = 1.0;
-      SB;
-      MF(9)  // S9: residual, diagonal, its reciprocal (process_qsos.m:192-198)
-      BREAD(8) BREAD(9)
-      const double r_ = fma(-absorb_, pmu_, py_);
-      const double a2_ = absorb_ * absorb_;
-      const double d_ = fma(pom_, a2_, pnu_);
-      double inv_d_ = __builtin_amdgcn_rcp(d_);
-      double ed = fma(-d_, inv_d_, 1.0);
-      inv_d_ = fma(inv_d_, ed, inv_d_);
-      ed = fma(-d_, inv_d_, 1.0);
-      inv_d_ = fma(inv_d_, ed, inv_d_);
-      SB;
-      MF(10)  // S10: MFMA weights of step rn, quadratic form and log-det accumulators
-      w_cur = a2_ * inv_d_;
-      u_cur = absorb_ * r_ * inv_d_;
-      quad_sum = fma(r_ * r_, inv_d_, quad_sum);
-      dprod *= d_;
-      dexp += __builtin_amdgcn_frexp_exp(dprod);
-      dprod = __builtin_amdgcn_frexp_mant(dprod);
-      near_c = near_;
-      lam_c = lamP_;
-      slot_c = (p_ + 12) & 15;
-      my_ring[slot_c] = raw_;
-      SB;
-      MF(11)
-      BREAD(10) BREAD(11)
-      SB;
-      MF(12)
-      SB;
-      MF(13)
-      BREAD(12) BREAD(13)
-      SB;
-      MF(14)
-      SB;
-      MF(15)
-      BREAD(14) BREAD(15)
-      SB;
-#undef MF
-#undef BREAD
-#undef SB
-    } else {
-      // generic line count: MFMAs of step t, then the unstaged prep
+  // The fp64 MFMA does not overlap with VALU work on its SIMD (tools/fp64_mix_probe.hip), so the
+  // loop is written for the fewest instructions, not for interleaving: per K-step one raw-profile
+  // value three steps ahead (wing tier branch-free; accurate tier under a wave-uniform vote), the
+  // 7-tap broadening from the doubled ring (no wrap-around: slots are compile-time), the weights,
+  // then 16 MFMAs.  Two waves per SIMD hide LDS and dependent-issue latency.
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) issue_chunk(c + 1);  // lands in the other buffer while we compute
+    const double *buf = stage + (size_t)(c & 1) * kChunkSteps * RD;
 #pragma unroll
-      for (int cc = 0; cc < NTW; ++cc)
-        acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? wa : ua, bop[cc], acc[cc], 0, 0, 0);
-      GPDLA_PREP(rec, rn)
+    for (int tt = 0; tt < kChunkSteps; ++tt) {
+      const int rn = c * kChunkSteps + tt;
+      if (rn < m.steps) {
+        const double *rec = buf + (size_t)tt * RD;
+        const double *extra = rec + NT * 64;
+        // ring slot of pixel 4 rn (+ jj, folded into my_ring); compile-time when chunks are 4 long
+        const int slot_p = kChunkSteps == 4 ? 4 * tt : ((4 * rn) & 15);
+        const int slot_w = (slot_p + 12) & 15;
+        // (1) raw profile three K-steps ahead: voigt.c:282-292
+        const double lamP = extra[16 + jj];
+        double total;
+        bool near;
+        if (LINES == 3) {
+          const double xa = fma(lamP, ms_r[0], -cs), xb = fma(lamP, ms_r[1], -cs),
+                       xc = fma(lamP, ms_r[LINES > 2 ? 2 : 0], -cs);
+          const double x2a = xa * xa, x2b = xb * xb, x2c = xc * xc;
+          near = (x2a < 900.0) | (x2b < 900.0) | (x2c < 900.0);
+          const double sa = x2a + g_lines.y2[0], sb = x2b + g_lines.y2[1], sc = x2c + g_lines.y2[2];
+          // one reciprocal for the three lines: 1/(sa sb sc), then peel
+          const double pab = sa * sb, pbc = sb * sc, pac = sa * sc;
+          const double rinv = fast_rcp(pab * sc);
+          const double ra = rinv * pbc, rb = rinv * pac, rc = rinv * pab;
+          double ta = fma(kT6, ra, kT5), tb = fma(kT6, rb, kT5), tc = fma(kT6, rc, kT5);
+          ta = fma(ta, ra, kT4); tb = fma(tb, rb, kT4); tc = fma(tc, rc, kT4);
+          ta = fma(ta, ra, kT3); tb = fma(tb, rb, kT3); tc = fma(tc, rc, kT3);
+          ta = fma(ta, ra, kT2); tb = fma(tb, rb, kT2); tc = fma(tc, rc, kT2);
+          ta = fma(ta, ra, kT1); tb = fma(tb, rb, kT1); tc = fma(tc, rc, kT1);
+          ta = fma(ta, ra, kT0); tb = fma(tb, rb, kT0); tc = fma(tc, rc, kT0);
+          ta = fma(g_lines.m2y2[0] * ra, ra, ta);
+          tb = fma(g_lines.m2y2[1] * rb, rb, tb);
+          tc = fma(g_lines.m2y2[2] * rc, rc, tc);
+          total = fma(g_lines.cwing[2], rc * tc, fma(g_lines.cwing[1], rb * tb, g_lines.cwing[0] * (ra * ta)));
+        } else {
+          total = 0.0;
+          near = false;
+          for (int j = 0; j < L; ++j) {
+            const double x = fma(lamP, my_mult[j] * inv_s, -cs);
+            const double x2 = x * x;
+            near |= x2 < 900.0;
+            total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
+          }
+        }
+        double raw = exp_table(nscale * total, exp_tab);
+#ifndef GPDLA_ABLATE_NOSLOW
+        if (__builtin_expect(__any(near), 0)) raw = GPDLA_RAW_ACCURATE(lamP);
+#endif
+#ifdef GPDLA_ABLATE_NOVOIGT
+        raw = lamP * 1e-4;
+#endif
+        my_ring[slot_w] = raw;
+        my_ring[slot_w + 16] = raw;
+        // B fragments of this step: requested now, consumed by the MFMAs after the weights
+        const double *bt = rec + (size_t)tile0 * 64 + lane;
+        double bop[NTW];
+#pragma unroll
+        for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads up here (the scheduler sinks them)
+        // (2) instrument broadening for pixel 4 rn + jj: voigt.c:297-299 (symmetric taps)
+        const double *g = my_ring + slot_p;
+        double absorb = fma(g[6], tap0, g[0] * tap0);
+        double ab2 = fma(g[5], tap1, g[1] * tap1);
+        absorb = fma(g[2], tap2, absorb);
+        ab2 = fma(g[4], tap2, ab2);
+        absorb = fma(g[3], tap3, absorb) + ab2;
+        if (is_null) absorb = 1.0;
+        // (3) weights: process_qsos.m:192-198 folded into log_mvnpdf_low_rank.m:11-15
+        const double py = extra[4 * jj], pmu = extra[4 * jj + 1], pom = extra[4 * jj + 2],
+                     pnu = extra[4 * jj + 3];
+        const double r = fma(-absorb, pmu, py);
+        const double a2 = absorb * absorb;
+        const double d = fma(pom, a2, pnu);
+        const double inv_d = fast_rcp(d);
+        const double w = a2 * inv_d;
+        const double u = absorb * r * inv_d;
+        quad_sum = fma(r * r, inv_d, quad_sum);
+        dprod *= d;  // Sum log d as the log of a running product, renormalised every step
+        dexp += __builtin_amdgcn_frexp_exp(dprod);
+        dprod = __builtin_amdgcn_frexp_mant(dprod);
+        // (4) rank-4 update of [B | v] on the matrix cores
+#ifdef GPDLA_ABLATE_NOMFMA
+#pragma unroll
+        for (int cc = 0; cc < NTW; ++cc) {
+          asm volatile("" ::"v"(bop[cc]));
+          if (cc < 2) acc[cc][0] += (cc < nw ? w : u) * bop[cc];
+        }
+#else
+#pragma unroll
+        for (int cc = 0; cc < NTW; ++cc)
+          acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? w : u, bop[cc], acc[cc], 0, 0, 0);
+#endif
+      }
     }
+    __syncthreads();  // (waits vmcnt(0) for the prefetched chunk first)
   }
-  __syncthreads();  // everyone is done with the stage buffers
-#undef GPDLA_PREP
+#undef GPDLA_RAW_ACCURATE
   // per-sample scalar sums: combine the four pixel phases jj of each sample
   double logd_sum = log(dprod) + (double)dexp * 0.6931471805599453;
   quad_sum += __shfl_xor(quad_sum, 16);
@@ -892,8 +821,8 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
     const double ld_s = __shfl(logd_sum, src_lane);
     const int64_t slot_s = slot0 + jj + 4 * r;
     const int32_t sample_s = __shfl(sample, src_lane);
-    const double ll = factor_round<NTW, TS, TW>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
-                                                q_s, ld_s, m.n_kept);
+    const double ll = factor_round<NTW, TS, TW, 0>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
+                                                   q_s, ld_s, m.n_kept);
     if (role == 0 && s == 0) {
       if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
       else if (slot_s == a.S) a.ll_no_dla[q] = ll;
