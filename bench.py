@@ -34,6 +34,24 @@ def algorithmic_flops(n: int, k: int) -> float:
     return n * k * (k + 3) + k ** 3 / 3.0
 
 
+def pmc_traffic(args):
+    """HBM bytes per k_sweep launch from the committed rocprofv3 --pmc summary (separate counter
+    passes, FETCH_SIZE doubled per the gfx950 rule; profiles/pmc_latest.json).  PMC collection
+    cannot run inside this process, so the figure is reported only when it was measured on the
+    same workload shape; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            p = json.load(f)
+        c = p["config"]
+        if (c["spectra"], c["pixels"], c["k"], c["dla_samples"]) == (args.spectra, args.pixels, args.k,
+                                                                     args.samples):
+            return float(p["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(model, samples, spectra, seconds_target=12.0):
     """The CPU oracle (literal as-written restatement of the reference path, OpenMP over samples
     like the reference's parfor) timed on this host: a bounded sample of the same workload --
@@ -172,7 +190,8 @@ def main():
                                       "the 12-column posterior table"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel": "k_sweep", "kernel_ms": sweep_ms,
+                         "traffic": pmc_traffic(args), "traffic_unit": "bytes/launch (rocprofv3 PMC, "
+                         "profiles/pmc_latest.json)", "kernel": "k_sweep", "kernel_ms": sweep_ms,
                          "flops_per_eval": algorithmic_flops(args.pixels, args.k)},
         }
         if args.pcie and world == 1:

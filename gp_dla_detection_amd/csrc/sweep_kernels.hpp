@@ -799,7 +799,11 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
 #endif
       }
     }
+#ifdef GPDLA_ABLATE_NOBARRIER
+    __builtin_amdgcn_s_waitcnt(0);  // timing experiment only: races on the stage buffers
+#else
     __syncthreads();  // (waits vmcnt(0) for the prefetched chunk first)
+#endif
   }
 #undef GPDLA_RAW_ACCURATE
   // per-sample scalar sums: combine the four pixel phases jj of each sample
