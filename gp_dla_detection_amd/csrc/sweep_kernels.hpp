@@ -577,6 +577,30 @@ __device__ __noinline__ double raw_accurate(double lamP, double m0, double m1, d
 // Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk,
 // TW tiles that take the weight w (the rest take u; TS*NTW tiles in all, zero-padded), LINES
 // number of Lyman lines when known at compile time (0: read num_lines at run time).
+// Wing-tier optical-depth sum for the three-line case (Ly-alpha, beta, gamma): FMA-form
+// velocities, ONE reciprocal for the three lines (1/(sa sb sc), then peeled), 6-term series.
+// Returns Sum_j lead_j y_j [Re w_j sqrt(pi)/y_j]; *near: some line within 30 Doppler widths.
+__device__ __forceinline__ double wing_sum3(double lamP, double msa, double msb, double msc, double cs,
+                                            bool *near) {
+  const double xa = fma(lamP, msa, -cs), xb = fma(lamP, msb, -cs), xc = fma(lamP, msc, -cs);
+  const double x2a = xa * xa, x2b = xb * xb, x2c = xc * xc;
+  *near = (x2a < 900.0) | (x2b < 900.0) | (x2c < 900.0);
+  const double sa = x2a + g_lines.y2[0], sb = x2b + g_lines.y2[1], sc = x2c + g_lines.y2[2];
+  const double pab = sa * sb, pbc = sb * sc, pac = sa * sc;
+  const double rinv = fast_rcp(pab * sc);
+  const double ra = rinv * pbc, rb = rinv * pac, rc = rinv * pab;
+  double ta = fma(kT6, ra, kT5), tb = fma(kT6, rb, kT5), tc = fma(kT6, rc, kT5);
+  ta = fma(ta, ra, kT4); tb = fma(tb, rb, kT4); tc = fma(tc, rc, kT4);
+  ta = fma(ta, ra, kT3); tb = fma(tb, rb, kT3); tc = fma(tc, rc, kT3);
+  ta = fma(ta, ra, kT2); tb = fma(tb, rb, kT2); tc = fma(tc, rc, kT2);
+  ta = fma(ta, ra, kT1); tb = fma(tb, rb, kT1); tc = fma(tc, rc, kT1);
+  ta = fma(ta, ra, kT0); tb = fma(tb, rb, kT0); tc = fma(tc, rc, kT0);
+  ta = fma(g_lines.m2y2[0] * ra, ra, ta);
+  tb = fma(g_lines.m2y2[1] * rb, rb, tb);
+  tc = fma(g_lines.m2y2[2] * rc, rc, tc);
+  return fma(g_lines.cwing[2], rc * tc, fma(g_lines.cwing[1], rb * tb, g_lines.cwing[0] * (ra * ta)));
+}
+
 constexpr int kRing2 = 33;   // doubled raw-profile ring: 32 slots + 1 pad per sample
 constexpr int kExpTab = 64;  // entries of the 2^(j/64) table behind exp_table()
 
@@ -678,9 +702,17 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
 
   __syncthreads();  // multipliers and the exp table visible
   // prime the ring with padded pixels 0..11 (the raw profile runs three K-steps ahead)
-#pragma unroll
   for (int c3 = 0; c3 < 3; ++c3) {
-    const double v = GPDLA_RAW_ACCURATE(lam[min(4 * c3 + jj, n_pad - 1)]);
+    const double lam0 = lam[min(4 * c3 + jj, n_pad - 1)];
+    double v;
+    if (LINES == 3) {
+      bool near0;
+      v = exp_table(nscale * wing_sum3(lam0, ms_r[0], ms_r[LINES > 1 ? 1 : 0], ms_r[LINES > 2 ? 2 : 0],
+                                       cs, &near0), exp_tab);
+      if (__any(near0)) v = GPDLA_RAW_ACCURATE(lam0);
+    } else {
+      v = GPDLA_RAW_ACCURATE(lam0);
+    }
     my_ring[4 * c3] = v;
     my_ring[4 * c3 + 16] = v;
   }
@@ -720,25 +752,7 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
         double total;
         bool near;
         if (LINES == 3) {
-          const double xa = fma(lamP, ms_r[0], -cs), xb = fma(lamP, ms_r[1], -cs),
-                       xc = fma(lamP, ms_r[LINES > 2 ? 2 : 0], -cs);
-          const double x2a = xa * xa, x2b = xb * xb, x2c = xc * xc;
-          near = (x2a < 900.0) | (x2b < 900.0) | (x2c < 900.0);
-          const double sa = x2a + g_lines.y2[0], sb = x2b + g_lines.y2[1], sc = x2c + g_lines.y2[2];
-          // one reciprocal for the three lines: 1/(sa sb sc), then peel
-          const double pab = sa * sb, pbc = sb * sc, pac = sa * sc;
-          const double rinv = fast_rcp(pab * sc);
-          const double ra = rinv * pbc, rb = rinv * pac, rc = rinv * pab;
-          double ta = fma(kT6, ra, kT5), tb = fma(kT6, rb, kT5), tc = fma(kT6, rc, kT5);
-          ta = fma(ta, ra, kT4); tb = fma(tb, rb, kT4); tc = fma(tc, rc, kT4);
-          ta = fma(ta, ra, kT3); tb = fma(tb, rb, kT3); tc = fma(tc, rc, kT3);
-          ta = fma(ta, ra, kT2); tb = fma(tb, rb, kT2); tc = fma(tc, rc, kT2);
-          ta = fma(ta, ra, kT1); tb = fma(tb, rb, kT1); tc = fma(tc, rc, kT1);
-          ta = fma(ta, ra, kT0); tb = fma(tb, rb, kT0); tc = fma(tc, rc, kT0);
-          ta = fma(g_lines.m2y2[0] * ra, ra, ta);
-          tb = fma(g_lines.m2y2[1] * rb, rb, tb);
-          tc = fma(g_lines.m2y2[2] * rc, rc, tc);
-          total = fma(g_lines.cwing[2], rc * tc, fma(g_lines.cwing[1], rb * tb, g_lines.cwing[0] * (ra * ta)));
+          total = wing_sum3(lamP, ms_r[0], ms_r[LINES > 1 ? 1 : 0], ms_r[LINES > 2 ? 2 : 0], cs, &near);
         } else {
           total = 0.0;
           near = false;
