@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--pixels", type=int, default=1500)
     ap.add_argument("--samples", type=int, default=10000)
     ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--contraction", choices=["f64", "f32"], default="f64",
+                    help="f32: BASELINE config 5's study variant (fp32 matrix-core contraction, fp64 "
+                         "everything else); not parity-grade, reports its max-abs delta vs f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the one-shot host-buffer entry point (H2D + sweep + D2H); "
@@ -124,7 +127,8 @@ def main():
     lp = gp.dla_existence_prior(cat["z_qsos"], cat["dla_ind"], z)
 
     stream = torch.cuda.Stream()
-    ctx = gp.Context(local_rank, stream=stream)
+    params = gp.Parameters(contraction_precision=1 if args.contraction == "f32" else 0)
+    ctx = gp.Context(local_rank, params=params, stream=stream)
     ctx.set_model(model)
     ctx.set_samples(samples)
     batch = ctx.upload(spectra, lp[0], lp[1])  # inputs resident in HBM before the timed region
@@ -180,7 +184,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if args.contraction == "f64" else "f32 contraction, f64 elsewhere",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic spectra, fused Voigt + low-rank "
                                    "log-evidence sweep, HBM-resident",
@@ -194,6 +198,19 @@ def main():
                          "profiles/pmc_latest.json)", "kernel": "k_sweep", "kernel_ms": sweep_ms,
                          "flops_per_eval": algorithmic_flops(args.pixels, args.k)},
         }
+        if args.contraction == "f32":
+            nchk = min(args.spectra, 4)
+            lpc = (lp[0][:nchk], lp[1][:nchk])
+            ref = gp.process_qsos(model, samples, spectra[:nchk], log_priors=lpc, device=local_rank)
+            got = gp.process_qsos(model, samples, spectra[:nchk], log_priors=lpc, device=local_rank,
+                                  params=params)
+            out["config"]["max_abs_delta_vs_f64"] = {
+                "sample_log_likelihoods_dla": float(np.nanmax(np.abs(
+                    got["sample_log_likelihoods_dla"] - ref["sample_log_likelihoods_dla"]))),
+                "log_likelihoods_dla": float(np.nanmax(np.abs(
+                    got["log_likelihoods_dla"] - ref["log_likelihoods_dla"]))),
+                "p_dlas": float(np.nanmax(np.abs(got["p_dlas"] - ref["p_dlas"]))),
+                "quasars_checked": nchk}
         if args.pcie and world == 1:
             n_pc = min(args.spectra, 128)
             t0 = time.perf_counter()

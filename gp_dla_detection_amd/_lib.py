@@ -61,7 +61,7 @@ class Config(C.Structure):
                 ("max_dlas", C.c_int32), ("num_forest_lines", C.c_int32),
                 ("min_z_separation", C.c_double), ("prev_tau_0", C.c_double),
                 ("prev_beta", C.c_double), ("rng_seed", C.c_uint64),
-                ("first_quasar_index", C.c_int64)]
+                ("first_quasar_index", C.c_int64), ("contraction_precision", C.c_int32)]
 
 
 class Results(C.Structure):

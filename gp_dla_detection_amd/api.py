@@ -42,7 +42,7 @@ def _config(params: Parameters) -> _lib.Config:
                  "max_z_cut", "min_z_cut", "width", "num_lines"):
         setattr(cfg, name, getattr(params, name))
     for name in ("max_dlas", "num_forest_lines", "min_z_separation", "prev_tau_0", "prev_beta",
-                 "rng_seed", "first_quasar_index"):
+                 "rng_seed", "first_quasar_index", "contraction_precision"):
         if hasattr(params, name):
             setattr(cfg, name, getattr(params, name))
     return cfg

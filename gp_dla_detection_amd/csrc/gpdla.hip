@@ -171,6 +171,7 @@ void gpdla_default_config(gpdla_config *cfg) {
   cfg->prev_beta = 3.65;                    // multi :37
   cfg->rng_seed = 0x9E3779B97F4A7C15ull;
   cfg->first_quasar_index = 0;
+  cfg->contraction_precision = 0;
 }
 
 /* ------------------------------ context ------------------------------ */
@@ -222,6 +223,8 @@ int gpdla_context_set_config(gpdla_context *c, const gpdla_config *cfg) {
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "width must be 3 (voigt.c:229 hard-codes the 7-tap profile)");
   if (cfg->num_lines < 1 || cfg->num_lines > kMaxLines)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "num_lines %d outside [1, 31]", cfg->num_lines);
+  if (cfg->contraction_precision != 0 && cfg->contraction_precision != 1)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "contraction_precision must be 0 (fp64) or 1 (fp32 study)");
   c->cfg = *cfg;
   return GPDLA_OK;
 }
@@ -417,24 +420,25 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
 
 namespace {
 
-template <int NTW, int TS, int CH, int TW, int LINES>
+template <typename T, int WAVES, int NTW, int TS, int CH, int TW, int LINES>
 int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
-  constexpr int groups = kSweepWaves / TS;
+  constexpr int groups = WAVES / TS;
   const int L = args.num_lines;
-  const size_t RD = (size_t)b->ntiles * 64 + 32;
+  const size_t RD = (size_t)record_doubles(b->ntiles, sizeof(T) == 4);
   const size_t stage_doubles = 2 * (size_t)CH * RD;
   const size_t epi_doubles = (size_t)groups * 4 * b->ntiles * 16;
-  if (epi_doubles > stage_doubles) return fail(GPDLA_ERR_UNSUPPORTED, "epilogue does not fit the stage buffers");
-  const size_t lds = (stage_doubles + (size_t)kSweepWaves * kSamplesPerWave * kRing2 + kExpTab +
-                      (size_t)groups * kSamplesPerWave * L) * sizeof(double);
+  // the epilogue reuses the whole dynamic array (stage buffers, then rings etc.: all dead by then)
+  const size_t loop_doubles = stage_doubles + (size_t)WAVES * kSamplesPerWave * kRing2 + kExpTab +
+                              (size_t)groups * kSamplesPerWave * L;
+  const size_t lds = std::max(loop_doubles, epi_doubles) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "sweep needs %zu B of LDS", lds);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<NTW, TS, CH, TW, LINES>),
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<T, WAVES, NTW, TS, CH, TW, LINES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   args.blocks_per_quasar = (int32_t)((b->S + 1 + groups * kSamplesPerWave - 1) / (groups * kSamplesPerWave));
   const int64_t nblocks = 8 * ((b->nq + 7) / 8) * (int64_t)args.blocks_per_quasar;
   if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "batch too large for one launch");
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  hipLaunchKernelGGL((k_sweep<NTW, TS, CH, TW, LINES>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  hipLaunchKernelGGL((k_sweep<T, WAVES, NTW, TS, CH, TW, LINES>), dim3((unsigned)nblocks), dim3(WAVES * 64), lds, c->stream, args);
   HIP_TRY(hipGetLastError());
   if (c->timing) {
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -452,7 +456,7 @@ extern "C" {
 namespace {
 
 // k_prepare + k_build_records for a batch (multi: the mean-flux / Lyman-series variant)
-int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi) {
+int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi, bool f32_tiles = false) {
   hipStream_t st = c->stream;
   Config cfg;
   cfg.min_lambda = c->cfg.min_lambda;
@@ -493,6 +497,7 @@ int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi) {
   ba.tiles_w = b->tiles_w;
   ba.ntiles = b->ntiles;
   ba.blocks_per_quasar = 16;
+  ba.f32_tiles = f32_tiles ? 1 : 0;
   hipLaunchKernelGGL(k_build_records, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
   HIP_TRY(hipGetLastError());
   return GPDLA_OK;
@@ -508,7 +513,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "model/samples changed after the batch was uploaded");
   HIP_TRY(hipSetDevice(c->device_id));
   hipStream_t st = c->stream;
-  int rc = launch_prepare(c, b, false);
+  int rc = launch_prepare(c, b, false, c->cfg.contraction_precision == 1);
   if (rc) return rc;
   const int num_lines = c->cfg.num_lines;
 
@@ -533,10 +538,15 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.ll_no_dla = b->d_ll_no;
   sa.blocks_per_quasar = 0;  // set by launch_sweep
   const bool three = num_lines == 3;
+  const bool f32 = c->cfg.contraction_precision == 1;
   if (b->k <= 20) {  // 14 w-tiles (<= 210 vech columns) + 2 u-tiles, zero-padded
-    rc = three ? launch_sweep<16, 1, 4, 14, 3>(c, b, sa) : launch_sweep<16, 1, 4, 14, 0>(c, b, sa);
-  } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles, split over 4 waves
-    rc = three ? launch_sweep<14, 4, 1, 52, 3>(c, b, sa) : launch_sweep<14, 4, 1, 52, 0>(c, b, sa);
+    if (!f32) rc = three ? launch_sweep<double, 8, 16, 1, 4, 14, 3>(c, b, sa) : launch_sweep<double, 8, 16, 1, 4, 14, 0>(c, b, sa);
+    else rc = three ? launch_sweep<float, 8, 16, 1, 4, 14, 3>(c, b, sa) : launch_sweep<float, 8, 16, 1, 4, 14, 0>(c, b, sa);
+  } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles
+    if (!f32)  // fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
+      rc = three ? launch_sweep<double, 8, 14, 4, 1, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
+    else       // fp32: 224 accumulator registers fit one wave (4-wave blocks, one wave per SIMD)
+      rc = three ? launch_sweep<float, 4, 56, 1, 4, 52, 3>(c, b, sa) : launch_sweep<float, 4, 56, 1, 4, 52, 0>(c, b, sa);
   } else {
     rc = fail(GPDLA_ERR_UNSUPPORTED, "k = %d needs %d B tiles (max 56)", b->k, b->ntiles);
   }

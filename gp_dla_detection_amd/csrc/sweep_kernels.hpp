@@ -29,6 +29,30 @@ namespace gpdla {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Precision of the [W | U] * [P | M] contraction.  double: v_mfma_f64_16x16x4_f64 (the shipped,
+// parity-grade path).  float: v_mfma_f32_16x16x4_f32 on the XDL matrix cores -- BASELINE config 5's
+// "fp32 mixed-precision variant with fp64 log-det accumulation": weights, quadratic form and log
+// determinant stay fp64, only B and v are accumulated in fp32 (a speed/accuracy study, not parity).
+// Both instructions take A[row l&15][k l>>4], B[k l>>4][col l&15]; the result maps differ:
+// f64: row = (l>>4) + 4 reg;  f32: row = 4 (l>>4) + reg  (col = l&15 in both).
+template <typename T> struct Mat;
+template <> struct Mat<double> {
+  using acc_t = d4;
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int sample_of(int jj, int r) { return jj + 4 * r; }
+};
+template <> struct Mat<float> {
+  using acc_t = f4;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int sample_of(int jj, int r) { return 4 * jj + r; }
+};
+
 constexpr int kMaxLines = 31;
 constexpr int kWavesPerBlock = 4;
 constexpr int kSamplesPerWave = 16;   // rows of the 16x16x4 MFMA
@@ -288,23 +312,29 @@ struct BuildRecordsArgs {
   double *records;        // pool, record index = pix_off/4 + step
   int32_t k, tiles_w, ntiles;
   int32_t blocks_per_quasar;
+  int32_t f32_tiles;      // 1: tiles stored as float (the fp32-contraction study), 0: double
 };
 
-__device__ __forceinline__ int record_doubles(int ntiles) { return ntiles * 64 + 32; }
+// doubles per record: tiles (64 elements each, as double or float) + 32 doubles of extras
+__host__ __device__ __forceinline__ int record_doubles(int ntiles, int f32_tiles) {
+  return ntiles * (f32_tiles ? 32 : 64) + 32;
+}
 
 __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
   const int q = blockIdx.x / a.blocks_per_quasar;
   const int bq = blockIdx.x % a.blocks_per_quasar;
   const QuasarMeta m = a.meta[q];
-  const int RD = record_doubles(a.ntiles);
-  const int64_t total = (int64_t)(m.steps + 1) * RD;
+  const int RD = record_doubles(a.ntiles, a.f32_tiles);
+  const int per_rec = a.ntiles * 64 + 32;  // logical elements per record
+  const int64_t total = (int64_t)(m.steps + 1) * per_rec;
   const int ncol_w = a.k * (a.k + 1) / 2;
   const int n_pad = m.n_u + 6;
   double *out = a.records + (m.pix_off / 4) * (int64_t)RD;
   for (int64_t e = (int64_t)bq * 256 + threadIdx.x; e < total;
        e += (int64_t)a.blocks_per_quasar * 256) {
-    const int step = (int)(e / RD);
-    const int rem = (int)(e - (int64_t)step * RD);
+    const int step = (int)(e / per_rec);
+    const int rem = (int)(e - (int64_t)step * per_rec);
+    double *rec = out + (int64_t)step * RD;
     double v = 0.0;
     if (rem < a.ntiles * 64) {
       const int tile = rem >> 6, l = rem & 63;
@@ -323,6 +353,8 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
         const int c = (tile - a.tiles_w) * 16 + col;
         if (c < a.k) v = row[c];
       }
+      if (a.f32_tiles) reinterpret_cast<float *>(rec)[rem] = (float)v;
+      else rec[rem] = v;
     } else {
       const int r2 = rem - a.ntiles * 64;
       if (r2 < 16) {
@@ -334,8 +366,8 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
         if (P > n_pad - 1) P = n_pad - 1;
         v = a.lam_pad[m.lam_off + P];
       }
+      rec[RD - 32 + r2] = v;
     }
-    out[e] = v;
   }
 }
 
@@ -360,7 +392,7 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
 // buffering) | raw-profile rings | per-sample line multipliers.  After the loop the chunk buffers
 // are reused by the Cholesky epilogue.
 // ------------------------------------------------------------------------------------------
-constexpr int kSweepWaves = 8;
+constexpr int kSweepWaves = 8;  // waves per block of the fp64 sweeps
 constexpr int kValuPerMfma = 10;  // VALU instructions scheduled behind each MFMA of the main loop
 
 struct SweepArgs {
@@ -484,14 +516,14 @@ __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, 
   return pd ? ll : NAN;
 }
 
-template <int NTW, int TS, int TW, int KC>
-__device__ __forceinline__ double factor_round(const d4 (&acc)[NTW], int r, double *e, int s,
+template <int NTW, int TS, int TW, int KC, typename ACC>
+__device__ __forceinline__ double factor_round(const ACC (&acc)[NTW], int r, double *e, int s,
                                                int role, int tile0, int k, double q_s, double ld_s,
                                                int n_kept) {
   constexpr int voff = TW * 16;
   if (TS > 1) __syncthreads();
 #pragma unroll
-  for (int cc = 0; cc < NTW; ++cc) e[(tile0 + cc) * 16 + s] = acc[cc][r];
+  for (int cc = 0; cc < NTW; ++cc) e[(tile0 + cc) * 16 + s] = (double)acc[cc][r];
   if (TS > 1) __syncthreads();
   else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -625,13 +657,15 @@ __device__ __forceinline__ double exp_table(double x, const double *tab) {
 // (must be 4: the step loop is unrolled over the chunk so ring slots are compile-time),
 // TW tiles that take the weight w (the rest take u; TS*NTW tiles in all, zero-padded), LINES
 // number of Lyman lines when known at compile time (0: read num_lines at run time).
-template <int NTW, int TS, int kChunkSteps, int TW, int LINES>
-__global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
+template <typename T, int WAVES, int NTW, int TS, int kChunkSteps, int TW, int LINES>
+__global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   extern __shared__ double smem[];
   static_assert(kChunkSteps == 4 || kChunkSteps == 1, "step loop is written for chunks of 4 (or 1)");
-  constexpr int GROUPS = kSweepWaves / TS;  // sample groups per block
+  constexpr int GROUPS = WAVES / TS;  // sample groups per block
   constexpr int NT = NTW * TS;
-  constexpr int RD = NT * 64 + 32;
+  constexpr int TD = 64 * (int)sizeof(T) / 8;  // doubles occupied by one 64-element tile
+  constexpr int RD = NT * TD + 32;
+  using acc_t = typename Mat<T>::acc_t;
   const int64_t xj = blockIdx.x >> 3;
   const int64_t q = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
   const int bq = (int)(xj % a.blocks_per_quasar);
@@ -644,8 +678,8 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   const int L = LINES > 0 ? LINES : a.num_lines;
 
   double *stage = smem;                                            // [2][kChunkSteps][RD]
-  double *ring = stage + (size_t)2 * kChunkSteps * RD;             // [8 waves][16][33]
-  double *exp_tab = ring + kSweepWaves * kSamplesPerWave * kRing2; // [64]
+  double *ring = stage + (size_t)2 * kChunkSteps * RD;             // [WAVES][16][33]
+  double *exp_tab = ring + WAVES * kSamplesPerWave * kRing2;       // [64]
   double *mult_s = exp_tab + kExpTab;                              // [GROUPS*16][L]
 
   const int64_t slot0 = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave;
@@ -681,7 +715,7 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
     const int units = csteps * (RD / 2);  // 16-byte units
     const double *src = rec_base + (size_t)c * kChunkSteps * RD;
     double *dst = stage + (size_t)(c & 1) * kChunkSteps * RD;
-    for (int i = wave; i * 64 < units; i += kSweepWaves) {
+    for (int i = wave; i * 64 < units; i += WAVES) {
       const int unit = i * 64 + lane;
       if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)i * 128);
     }
@@ -717,9 +751,9 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
     my_ring[4 * c3 + 16] = v;
   }
 
-  d4 acc[NTW];
+  acc_t acc[NTW];
 #pragma unroll
-  for (int c = 0; c < NTW; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < NTW; ++c) acc[c] = acc_t{0, 0, 0, 0};
   double quad_sum = 0.0, dprod = 1.0;
   int dexp = 0;
   const int tile0 = role * NTW;
@@ -743,7 +777,7 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
       const int rn = c * kChunkSteps + tt;
       if (rn < m.steps) {
         const double *rec = buf + (size_t)tt * RD;
-        const double *extra = rec + NT * 64;
+        const double *extra = rec + NT * TD;
         // ring slot of pixel 4 rn (+ jj, folded into my_ring); compile-time when chunks are 4 long
         const int slot_p = kChunkSteps == 4 ? 4 * tt : ((4 * rn) & 15);
         const int slot_w = (slot_p + 12) & 15;
@@ -773,8 +807,8 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
         my_ring[slot_w] = raw;
         my_ring[slot_w + 16] = raw;
         // B fragments of this step: requested now, consumed by the MFMAs after the weights
-        const double *bt = rec + (size_t)tile0 * 64 + lane;
-        double bop[NTW];
+        const T *bt = reinterpret_cast<const T *>(rec) + (size_t)tile0 * 64 + lane;
+        T bop[NTW];
 #pragma unroll
         for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
         __builtin_amdgcn_sched_barrier(0);  // keep the reads up here (the scheduler sinks them)
@@ -804,12 +838,12 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
 #pragma unroll
         for (int cc = 0; cc < NTW; ++cc) {
           asm volatile("" ::"v"(bop[cc]));
-          if (cc < 2) acc[cc][0] += (cc < nw ? w : u) * bop[cc];
+          if (cc < 2) acc[cc][0] += (T)(cc < nw ? w : u) * bop[cc];
         }
 #else
 #pragma unroll
         for (int cc = 0; cc < NTW; ++cc)
-          acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? w : u, bop[cc], acc[cc], 0, 0, 0);
+          acc[cc] = Mat<T>::mfma((T)(cc < nw ? w : u), bop[cc], acc[cc]);
 #endif
       }
     }
@@ -833,11 +867,13 @@ __global__ __launch_bounds__(512) void k_sweep(SweepArgs a) {
   double *Eg = stage + (size_t)group * 4 * ncols;  // [4 samples][ncols] for this sample group
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    // scalars of sample jj + 4r live in the lanes whose s equals jj + 4r
-    const int src_lane = (jj + 4 * r) + 16 * jj;
+    // register r of lane group jj holds sample sigma of the wave's 16; its scalars live in the
+    // lanes whose s equals sigma
+    const int sigma = Mat<T>::sample_of(jj, r);
+    const int src_lane = sigma + 16 * jj;
     const double q_s = __shfl(quad_sum, src_lane);
     const double ld_s = __shfl(logd_sum, src_lane);
-    const int64_t slot_s = slot0 + jj + 4 * r;
+    const int64_t slot_s = slot0 + sigma;
     const int32_t sample_s = __shfl(sample, src_lane);
     const double ll = factor_round<NTW, TS, TW, 0>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
                                                    q_s, ld_s, m.n_kept);

@@ -33,6 +33,8 @@ class Parameters:
     num_lines: int = 3                     # :63
     max_z_cut: float = kms_to_z(3000)      # :65
     min_z_cut: float = kms_to_z(3000)      # :69
+    # 0: fp64 contraction (parity-grade, default); 1: fp32-matrix-core study variant (BASELINE config 5)
+    contraction_precision: int = 0
 
     def min_z_dla(self, wavelengths, z_qso):
         """set_parameters.m:70-73"""

@@ -118,6 +118,10 @@ typedef struct {
    * index, so shards of one run pass their global offset here and agree with an unsharded run */
   uint64_t rng_seed;
   int64_t first_quasar_index;
+  /* 0 (default): the [W|U]*[P|M] contraction in fp64 (parity-grade).  1: BASELINE config 5's study
+   * variant -- contraction on the fp32 matrix cores, everything else (Voigt profile, weights,
+   * quadratic form, log-determinant, Cholesky) in fp64.  Not parity-grade; single-DLA sweep only. */
+  int32_t contraction_precision;
 } gpdla_config;
 
 /* Fills a gpdla_config with the reference's defaults (set_parameters.m / set_parameters_multi.m). */

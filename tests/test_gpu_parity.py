@@ -252,3 +252,20 @@ def test_resident_batch_is_idempotent(model20):
     np.testing.assert_array_equal(t.cpu().numpy()[:, 5], a["log_likelihoods_dla"])
     batch.close()
     ctx.close()
+
+
+def test_fp32_contraction_study_variant(model20):
+    """BASELINE config 5: contraction on the fp32 matrix cores, the rest in fp64.  Not parity-grade:
+    the test only bounds its deviation from the fp64 path (k = 20 and the single-wave k = 40 form)."""
+    for k, model in ((20, model20), (40, synthetic.make_model(40))):
+        samples = synthetic.make_samples(300)
+        spectra = synthetic.make_spectra(2, 500, model, first_index=300)
+        lp = flat_priors(2)
+        ref = gp.process_qsos(model, samples, spectra, log_priors=lp)
+        got = gp.process_qsos(model, samples, spectra, log_priors=lp,
+                              params=gp.Parameters(contraction_precision=1))
+        d = np.abs(got["sample_log_likelihoods_dla"] - ref["sample_log_likelihoods_dla"])
+        scale = np.abs(ref["sample_log_likelihoods_dla"]).max()
+        assert np.isfinite(got["sample_log_likelihoods_dla"]).all()
+        assert d.max() < 1e-3 * scale, (k, d.max(), scale)   # fp32 accumulation over n pixels
+        assert np.abs(got["min_z_dlas"] - ref["min_z_dlas"]).max() == 0
