@@ -288,33 +288,46 @@ class Batch:
 
 def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None = None,
                  params: Parameters | None = None, device: int = 0,
-                 log_priors: tuple | None = None) -> dict:
+                 log_priors: tuple | None = None, max_quasars_per_batch: int | None = None) -> dict:
     """The ``process_qsos`` script (process_qsos.m:4-250) for a list of quasars.
 
     ``spectra``: list of dicts with ``wavelengths, flux, noise_variance, pixel_mask, z_qso`` (one
     entry of the ``all_*`` cell arrays each, after the ``test_ind`` subset of :56-61).
     ``prior_catalog``: ``{"z_qsos", "dla_ind"}`` of the training release after the Lyman-limit
     filter of :15-25; or pass ``log_priors=(log_priors_no_dla, log_priors_dla)`` directly.
+    Quasars are independent, so a long list is swept in HBM-resident batches of at most
+    ``max_quasars_per_batch`` (default: sized to ~64 GiB of step records).
     Returns the variables the script saves (:236-244)."""
     p = params or Parameters()
-    csr = spectra_to_csr(spectra)
+    spectra = list(spectra)
+    z_all = np.array([float(s["z_qso"]) for s in spectra], dtype=np.float64)
     if log_priors is None:
         if prior_catalog is None:
             raise ValueError("need prior_catalog or log_priors")
-        log_priors = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"],
-                                         csr["z_qsos"], p)
+        log_priors = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], z_all, p)
+    lp_no, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
+    if max_quasars_per_batch is None:
+        longest = max((np.asarray(s["wavelengths"]).size for s in spectra), default=1)
+        per_quasar = (longest / 4 + 2) * (16 * 64 + 32) * 8  # bytes of step records (k <= 20)
+        if model["M"].shape[1] > 20:
+            per_quasar *= 3.5
+        max_quasars_per_batch = max(1, int(64 * 2**30 / per_quasar))
     ctx = Context(device, p)
+    parts = []
     try:
         ctx.set_model(model)
         ctx.set_samples(samples)
-        batch = ctx.upload(csr, log_priors[0], log_priors[1])
-        try:
-            batch.process()
-            out = batch.download()
-        finally:
-            batch.close()
+        for lo in range(0, len(spectra), max_quasars_per_batch):
+            hi = min(lo + max_quasars_per_batch, len(spectra))
+            batch = ctx.upload(spectra[lo:hi], lp_no[lo:hi], lp_dla[lo:hi])
+            try:
+                batch.process()
+                parts.append(batch.download())
+            finally:
+                batch.close()
     finally:
         ctx.close()
+    out = {key: np.concatenate([part[key] for part in parts], axis=0) for key in parts[0]} if parts else {}
     out["num_lines"] = p.num_lines
     out["prior_z_qso_increase"] = p.prior_z_qso_increase
     out["max_z_cut"] = p.max_z_cut

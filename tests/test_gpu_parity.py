@@ -269,3 +269,49 @@ def test_fp32_contraction_study_variant(model20):
         assert np.isfinite(got["sample_log_likelihoods_dla"]).all()
         assert d.max() < 1e-3 * scale, (k, d.max(), scale)   # fp32 accumulation over n pixels
         assert np.abs(got["min_z_dlas"] - ref["min_z_dlas"]).max() == 0
+
+
+def test_tiny_and_odd_shapes(oracle, model20):
+    """Edge shapes: fewer pixels than one K-step, pixel counts not divisible by 4, and sample
+    counts around the 16-slot wave / 128-slot block boundaries (1, 15, 16, 17, 127, 128, 129)."""
+    for n in (1, 3, 5, 9):
+        samples = synthetic.make_samples(7)
+        sp = synthetic.make_spectrum(400 + n, n, model20, edge_pixels=1)
+        out = run_gpu(model20, samples, [sp])
+        ref = run_oracle(oracle, model20, samples, sp)
+        assert out["status"][0] == 0
+        assert abs(out["log_likelihoods_no_dla"][0] - ref["log_likelihood_no_dla"]) < TOL, n
+        assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL, n
+    sp = synthetic.make_spectrum(450, 222, model20, mask_fraction=0.05)
+    for S in (1, 15, 16, 17, 127, 128, 129):
+        samples = synthetic.make_samples(S)
+        out = run_gpu(model20, samples, [sp])
+        ref = run_oracle(oracle, model20, samples, sp)
+        assert out["sample_log_likelihoods_dla"].shape == (1, S)
+        assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL, S
+        assert abs(out["log_likelihoods_dla"][0] - ref["log_likelihood_dla"]) < TOL, S
+
+
+def test_bad_pixels_in_kept_data_propagate_like_the_reference(oracle, model20):
+    """A NaN flux in an UNMASKED pixel poisons that quasar only (NaN log-likelihoods, as MATLAB
+    arithmetic would give), not its neighbours in the batch."""
+    samples = synthetic.make_samples(24)
+    a = synthetic.make_spectrum(460, 210, model20)
+    b = synthetic.make_spectrum(461, 230, model20)
+    a["flux"] = a["flux"].copy()
+    a["flux"][100] = np.nan
+    out = run_gpu(model20, samples, [a, b])
+    assert np.isnan(out["sample_log_likelihoods_dla"][0]).all() and np.isnan(out["log_likelihoods_no_dla"][0])
+    ref = run_oracle(oracle, model20, samples, b)
+    assert np.abs(out["sample_log_likelihoods_dla"][1] - ref["sample_log_likelihoods_dla"]).max() < TOL
+
+
+def test_chunked_driver_matches_single_batch(model20):
+    """process_qsos splits a long quasar list into memory-bounded batches; results are identical."""
+    samples = synthetic.make_samples(64)
+    spectra = synthetic.make_spectra(7, 260, model20, first_index=470)
+    lp = flat_priors(7)
+    one = gp.process_qsos(model20, samples, spectra, log_priors=lp)
+    many = gp.process_qsos(model20, samples, spectra, log_priors=lp, max_quasars_per_batch=3)
+    for key in ("sample_log_likelihoods_dla", "log_likelihoods_dla", "model_posteriors", "status"):
+        np.testing.assert_array_equal(one[key], many[key])
