@@ -111,9 +111,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # GPDLA_BENCH_REHEARSAL=1: rehearse the multi-process path on a box with ONE GPU (every rank on
+    # cuda:0, gloo instead of RCCL, the gather staged through host memory).  Never used by the driver.
+    rehearsal = os.environ.get("GPDLA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     model = synthetic.make_model(args.k)
     samples = synthetic.make_samples(args.samples)
@@ -139,7 +147,8 @@ def main():
         with torch.cuda.stream(stream):
             batch.process()
             if world > 1:
-                gather_summaries(batch.summary_tensor(), counts)
+                table = batch.summary_tensor()
+                gather_summaries(table.cpu() if rehearsal else table, counts)
 
     def fence():
         torch.cuda.synchronize()
@@ -160,7 +169,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     sweep_ms = float(np.mean(kernel_ms))
