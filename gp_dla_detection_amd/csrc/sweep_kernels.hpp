@@ -54,9 +54,7 @@ template <> struct Mat<float> {
 };
 
 constexpr int kMaxLines = 31;
-constexpr int kWavesPerBlock = 4;
 constexpr int kSamplesPerWave = 16;   // rows of the 16x16x4 MFMA
-constexpr int kRingStride = 17;       // doubles per sample row of the raw-profile ring (16 + pad)
 constexpr double kLog2Pi = 1.83787706640934534;  // log_mvnpdf_low_rank.m:7
 
 // Lyman-series constants in device constant memory (filled once per process from
@@ -393,7 +391,6 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
 // are reused by the Cholesky epilogue.
 // ------------------------------------------------------------------------------------------
 constexpr int kSweepWaves = 8;  // waves per block of the fp64 sweeps
-constexpr int kValuPerMfma = 10;  // VALU instructions scheduled behind each MFMA of the main loop
 
 struct SweepArgs {
   const QuasarMeta *meta;
@@ -534,53 +531,6 @@ __device__ __forceinline__ double factor_round(const ACC (&acc)[NTW], int r, dou
 #else
   return role == 0 ? factor_lds<KC>(e, s, k, voff, q_s, ld_s, n_kept) : NAN;
 #endif
-}
-
-// Sum over the Lyman lines of lead_j * Re w_j * sqrt(pi) at one padded pixel (voigt.c:285-289).
-// LINES > 0: constants and multipliers live in registers (arrays indexed by unrolled j);
-// LINES == 0: run-time line count, constants from __constant__ memory, multipliers from LDS.
-// ACCURATE = false: branch-free wing formula for every line; *near is set when this lane is
-// within 30 Doppler widths of some line centre (the wing formula is then not valid).
-// ACCURATE = true: the three-tier rew_full for every line.
-template <int LINES, bool ACCURATE>
-__device__ __forceinline__ double line_sum(double lamP, const double *mult, int L, double c_light,
-                                           double inv_s, const double *ly, const double *ly2,
-                                           const double *llead, bool *near) {
-  double total = 0.0;
-  bool nr = false;
-  if (LINES > 0) {
-#pragma unroll
-    for (int j = 0; j < LINES; ++j) {
-      const double velocity = lamP * mult[j] - c_light;  // voigt.c:287 (two roundings)
-      const double x = velocity * inv_s;
-      double v;
-      if (ACCURATE) {
-        v = rew_full(x, ly[j]) * 1.7724538509055159;  // * sqrt(pi)
-      } else {
-        const double x2 = x * x;
-        nr |= x2 < 900.0;
-        v = ly[j] * wing_core(x2, ly2[j]);
-      }
-      total = fma(llead[j], v, total);
-    }
-  } else {
-    for (int j = 0; j < L; ++j) {
-      const double velocity = lamP * mult[j] - c_light;
-      const double x = velocity * inv_s;
-      const double yj = g_lines.y[j];
-      double v;
-      if (ACCURATE) {
-        v = rew_full(x, yj) * 1.7724538509055159;
-      } else {
-        const double x2 = x * x;
-        nr |= x2 < 900.0;
-        v = yj * wing_core(x2, yj * yj);
-      }
-      total = fma(g_lines.leading[j], v, total);
-    }
-  }
-  if (near) *near = nr;
-  return total;
 }
 
 // Accurate tier of the raw profile, out of line on purpose: it runs for ~5 % of the K-steps, and
