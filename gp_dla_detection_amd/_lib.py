@@ -107,6 +107,10 @@ SYMBOLS = [
     ("gpdla_context_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("gpdla_process_batch_multi", C.c_int, [C.POINTER(Model), C.POINTER(Samples), C.POINTER(Spectra),
                                             _u32p, C.POINTER(Config), C.POINTER(ResultsMulti), C.c_int]),
+    ("gpdla_training_create", C.c_int, [C.c_int, C.c_int64, C.c_int64, _dp, _dp, _dp,
+                                        C.POINTER(C.c_void_p)]),
+    ("gpdla_training_objective", C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
+    ("gpdla_training_destroy", None, [C.c_void_p]),
 ]
 
 _lib = None
@@ -114,7 +118,8 @@ _lib = None
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/gpdla.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("gpdla.hip", "sweep_kernels.hpp", "faddeeva.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("gpdla.hip", "sweep_kernels.hpp", "multi_kernels.hpp",
+                                            "training_kernels.hpp", "faddeeva.hpp")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("gpdla.h", "gpdla_lyman_series.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):

@@ -16,6 +16,7 @@
 #include "../../include/gpdla.h"
 #include "../../include/gpdla_lyman_series.h"
 #include "multi_kernels.hpp"
+#include "training_kernels.hpp"
 
 using namespace gpdla;
 
@@ -971,6 +972,116 @@ int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *sam
   gpdla_batch_destroy(b);
   gpdla_context_destroy(c);
   return rc;
+}
+
+/* ------------------------------ training objective (N3) ------------------------------ */
+
+}  // extern "C"
+
+struct gpdla_training {
+  int device_id = 0;
+  int64_t nq = 0, G = 0;
+  double *d_flux = nullptr, *d_lya = nullptr, *d_noise = nullptr;
+  double *d_x = nullptr, *d_g = nullptr, *d_omega2 = nullptr, *d_f = nullptr;
+  int32_t *d_flag = nullptr;
+  int64_t x_capacity = 0;
+};
+
+extern "C" {
+
+void gpdla_training_destroy(gpdla_training *t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device_id);
+  (void)hipDeviceSynchronize();
+  for (void *p : {(void *)t->d_flux, (void *)t->d_lya, (void *)t->d_noise, (void *)t->d_x, (void *)t->d_g,
+                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag})
+    dev_free(p);
+  delete t;
+}
+
+int gpdla_training_create(int device_id, int64_t nq, int64_t G, const double *flux, const double *lya,
+                          const double *noise, gpdla_training **out) {
+  if (!out || !flux || !lya || !noise) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (nq < 1 || G < 1) return fail(GPDLA_ERR_INVALID_ARGUMENT, "empty training set");
+  int rc = select_device(device_id);
+  if (rc) return rc;
+  gpdla_training *t = new gpdla_training();
+  t->device_id = device_id;
+  t->nq = nq;
+  t->G = G;
+  // MATLAB column-major [nq x G] -> quasar-major [nq][G] (one block streams one quasar)
+  const size_t n = (size_t)nq * G;
+  std::vector<double> tmp(n);
+  auto up = [&](const double *src, double **dst) -> int {
+    for (int64_t i = 0; i < nq; ++i)
+      for (int64_t p = 0; p < G; ++p) tmp[(size_t)i * G + p] = src[i + p * nq];
+    int r = dev_alloc(dst, n);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(*dst, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    return GPDLA_OK;
+  };
+  if ((rc = up(flux, &t->d_flux)) || (rc = up(lya, &t->d_lya)) || (rc = up(noise, &t->d_noise)) ||
+      (rc = dev_alloc(&t->d_omega2, (size_t)G)) || (rc = dev_alloc(&t->d_f, 1)) ||
+      (rc = dev_alloc(&t->d_flag, 1))) {
+    gpdla_training_destroy(t);
+    return rc;
+  }
+  *out = t;
+  return GPDLA_OK;
+}
+
+int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *f, double *g) {
+  if (!t || !x || !f || !g) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (k < 1 || k > GPDLA_MAX_K) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, GPDLA_MAX_K);
+  HIP_TRY(hipSetDevice(t->device_id));
+  const int64_t G = t->G;
+  const int64_t nx = G * (k + 1) + 3;
+  if (nx > t->x_capacity) {
+    dev_free(t->d_x);
+    dev_free(t->d_g);
+    t->d_x = t->d_g = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&t->d_x, (size_t)nx)) || (rc = dev_alloc(&t->d_g, (size_t)nx))) return rc;
+    t->x_capacity = nx;
+  }
+  HIP_TRY(hipMemcpy(t->d_x, x, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(t->d_g, 0, (size_t)nx * sizeof(double)));
+  HIP_TRY(hipMemset(t->d_f, 0, sizeof(double)));
+  HIP_TRY(hipMemset(t->d_flag, 0, sizeof(int32_t)));
+  hipLaunchKernelGGL(k_training_omega2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, 0,
+                     t->d_x + G * k, G, t->d_omega2);
+  TrainingArgs a;
+  a.nq = t->nq;
+  a.G = G;
+  a.k = k;
+  a.flux = t->d_flux;
+  a.lya_1pz = t->d_lya;
+  a.noise = t->d_noise;
+  a.M = t->d_x;
+  a.omega2 = t->d_omega2;
+  a.c_0 = std::exp(x[G * (k + 1)]);       // objective.m:30-32
+  a.tau_0 = std::exp(x[G * (k + 1) + 1]);
+  a.beta = std::exp(x[G * (k + 1) + 2]);
+  a.f = t->d_f;
+  a.g = t->d_g;
+  a.not_pd = t->d_flag;
+  const size_t lds = (size_t)(3 * G + 2 * k * k + 3 * k + 8) * sizeof(double);
+  if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "training kernel needs %zu B of LDS", lds);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_training_loss),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_training_loss, dim3((unsigned)t->nq), dim3(256), lds, 0, a);
+  HIP_TRY(hipGetLastError());
+  int32_t flag = 0;
+  HIP_TRY(hipMemcpy(g, t->d_g, (size_t)nx * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(f, t->d_f, sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&flag, t->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (flag) return fail(GPDLA_ERR_NOT_POSITIVE_DEFINITE, "B = I + M' D^-1 M not positive definite for some quasar");
+  // priors of Kim et al. (2007) on tau0 and beta, gradient only (objective.m:59-71)
+  const double tau_0_mu = 0.0023, tau_0_sigma = 0.0007, beta_mu = 3.65, beta_sigma = 0.21;
+  g[G * (k + 1) + 1] += a.tau_0 * (a.tau_0 - tau_0_mu) / (tau_0_sigma * tau_0_sigma);
+  g[G * (k + 1) + 2] += a.beta * (a.beta - beta_mu) / (beta_sigma * beta_sigma);
+  return GPDLA_OK;
 }
 
 }  // extern "C"

@@ -227,6 +227,21 @@ int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *sam
                               const gpdla_config *config, gpdla_results_multi *results,
                               int device_id);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training objective: objective.m:12-75 over spectrum_loss.m:14-76.
+ * The training set stays resident in HBM; each call evaluates f(x) and g(x) = df/dx for
+ * x = [vec M (G x k, column-major); log omega (G); log c0; log tau0; log beta] (objective.m:5),
+ * including the Kim et al. priors the reference adds to the gradient (:59-71).
+ * The three data matrices are [num_quasars x num_pixels] column-major as MATLAB holds them, NaN =
+ * missing pixel (:42).  Returns GPDLA_ERR_NOT_POSITIVE_DEFINITE where chol would throw (:42).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gpdla_training gpdla_training;
+int gpdla_training_create(int device_id, int64_t num_quasars, int64_t num_pixels,
+                          const double *centered_rest_fluxes, const double *lya_1pzs,
+                          const double *rest_noise_variances, gpdla_training **out);
+int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *f, double *g);
+void gpdla_training_destroy(gpdla_training *t);
+
 #ifdef __cplusplus
 }
 #endif

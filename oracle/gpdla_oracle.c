@@ -612,3 +612,217 @@ int gpdla_oracle_process_spectrum_multi(
   free_selection(&s);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Training objective: spectrum_loss.m:14-76 and objective.m:12-75,
+ * as written.  M is n x k column-major; dM likewise.
+ * ------------------------------------------------------------------------------------------ */
+int gpdla_oracle_spectrum_loss(const double *y, const double *lya_1pz, const double *noise_variance,
+                               const double *M, const double *omega2, int64_t n, int k, double c_0,
+                               double tau_0, double beta, double *nlog_p, double *dM,
+                               double *dlog_omega, double *dlog_c_0, double *dlog_tau_0,
+                               double *dlog_beta) {
+  const double log_2pi = 1.83787706640934534; /* :17 */
+  size_t nn = (size_t)n;
+  double *lya_optical_depth = (double *)malloc(sizeof(double) * nn);
+  double *lya_absorption = (double *)malloc(sizeof(double) * nn);
+  double *scaling_factor = (double *)malloc(sizeof(double) * nn);
+  double *absorption_noise = (double *)malloc(sizeof(double) * nn);
+  double *d = (double *)malloc(sizeof(double) * nn);
+  double *d_inv = (double *)malloc(sizeof(double) * nn);
+  double *D_inv_y = (double *)malloc(sizeof(double) * nn);
+  double *D_inv_M = (double *)malloc(sizeof(double) * nn * k);
+  double *B = (double *)calloc((size_t)k * k, sizeof(double));
+  double *R = (double *)calloc((size_t)k * k, sizeof(double));
+  double *C = (double *)malloc(sizeof(double) * nn * k); /* k x n, column-major */
+  double *Cy = (double *)calloc((size_t)k, sizeof(double));
+  double *CM = (double *)calloc((size_t)k * k, sizeof(double)); /* C * M, k x k */
+  double *K_inv_y = (double *)malloc(sizeof(double) * nn);
+  double *K_inv_M = (double *)malloc(sizeof(double) * nn * k);
+  double *diag_K_inv = (double *)malloc(sizeof(double) * nn);
+  double *yM = (double *)calloc((size_t)k, sizeof(double));
+  int rc = 0;
+  for (int64_t i = 0; i < n; i++) {
+    lya_optical_depth[i] = tau_0 * pow(lya_1pz[i], beta);                 /* :22 */
+    lya_absorption[i] = exp(-lya_optical_depth[i]);                       /* :23 */
+    scaling_factor[i] = 1 - lya_absorption[i] + c_0;                      /* :26 */
+    absorption_noise[i] = omega2[i] * (scaling_factor[i] * scaling_factor[i]); /* :27 */
+    d[i] = noise_variance[i] + absorption_noise[i];                       /* :29 */
+    d_inv[i] = 1.0 / d[i];                                                /* :31 */
+    D_inv_y[i] = d_inv[i] * y[i];                                         /* :32 */
+    for (int a = 0; a < k; a++) D_inv_M[i + a * nn] = d_inv[i] * M[i + a * nn]; /* :33 */
+  }
+  for (int a = 0; a < k; a++) /* :40 */
+    for (int b = 0; b < k; b++) {
+      double acc = 0.0;
+      for (int64_t i = 0; i < n; i++) acc += M[i + a * nn] * D_inv_M[i + b * nn];
+      B[a + b * k] = acc;
+    }
+  for (int a = 0; a < k; a++) B[a + a * k] += 1.0; /* :41 */
+  for (int j = 0; j < k && !rc; j++) {             /* :42 chol, upper */
+    double s = B[j + j * k];
+    for (int m = 0; m < j; m++) s -= R[m + j * k] * R[m + j * k];
+    if (!(s > 0.0)) { rc = -1; break; }
+    double rjj = sqrt(s);
+    R[j + j * k] = rjj;
+    for (int i = j + 1; i < k; i++) {
+      double t = B[j + i * k];
+      for (int m = 0; m < j; m++) t -= R[m + j * k] * R[m + i * k];
+      R[j + i * k] = t / rjj;
+    }
+  }
+  if (rc) { *nlog_p = NAN; goto done; }
+  for (int64_t i = 0; i < n; i++) { /* :44  C = L \ (L' \ D_inv_M') */
+    double *c = C + (size_t)i * k;
+    for (int a = 0; a < k; a++) {
+      double t = D_inv_M[i + a * nn];
+      for (int m = 0; m < a; m++) t -= R[m + a * k] * c[m];
+      c[a] = t / R[a + a * k];
+    }
+    for (int a = k - 1; a >= 0; a--) {
+      double t = c[a];
+      for (int m = a + 1; m < k; m++) t -= R[a + m * k] * c[m];
+      c[a] = t / R[a + a * k];
+    }
+  }
+  for (int64_t i = 0; i < n; i++)
+    for (int a = 0; a < k; a++) Cy[a] += C[(size_t)i * k + a] * y[i];
+  double quad = 0.0, log_det_K = 0.0;
+  for (int64_t i = 0; i < n; i++) { /* :46 */
+    double t = 0.0;
+    for (int a = 0; a < k; a++) t += D_inv_M[i + a * nn] * Cy[a];
+    K_inv_y[i] = D_inv_y[i] - t;
+    quad += y[i] * K_inv_y[i];
+    log_det_K += log(d[i]);
+  }
+  {
+    double sld = 0.0;
+    for (int a = 0; a < k; a++) sld += log(R[a + a * k]);
+    log_det_K += 2 * sld; /* :48 */
+  }
+  *nlog_p = 0.5 * (quad + log_det_K + (double)n * log_2pi); /* :52 */
+  /* :55  K_inv_M = D_inv_M - D_inv_M * (C * M) */
+  for (int a = 0; a < k; a++)
+    for (int b = 0; b < k; b++) {
+      double acc = 0.0;
+      for (int64_t i = 0; i < n; i++) acc += C[(size_t)i * k + a] * M[i + b * nn];
+      CM[a + b * k] = acc;
+    }
+  for (int64_t i = 0; i < n; i++)
+    for (int b = 0; b < k; b++) {
+      double t = 0.0;
+      for (int a = 0; a < k; a++) t += D_inv_M[i + a * nn] * CM[a + b * k];
+      K_inv_M[i + b * nn] = D_inv_M[i + b * nn] - t;
+    }
+  for (int64_t i = 0; i < n; i++)
+    for (int b = 0; b < k; b++) yM[b] += K_inv_y[i] * M[i + b * nn];
+  for (int64_t i = 0; i < n; i++) /* :56 */
+    for (int b = 0; b < k; b++) dM[i + b * nn] = -(K_inv_y[i] * yM[b] - K_inv_M[i + b * nn]);
+  *dlog_c_0 = *dlog_tau_0 = *dlog_beta = 0.0;
+  double c1 = 0, c2 = 0, t1 = 0, t2 = 0, b1 = 0, b2 = 0;
+  for (int64_t i = 0; i < n; i++) {
+    double s = 0.0;
+    for (int a = 0; a < k; a++) s += C[(size_t)i * k + a] * D_inv_M[i + a * nn];
+    diag_K_inv[i] = d_inv[i] - s;                                                     /* :59 */
+    dlog_omega[i] = -(absorption_noise[i] * (K_inv_y[i] * K_inv_y[i] - diag_K_inv[i])); /* :62 */
+    double da = c_0 * omega2[i] * scaling_factor[i];                                  /* :65 */
+    c1 += (K_inv_y[i] * da) * K_inv_y[i];
+    c2 += diag_K_inv[i] * da;
+    da = omega2[i] * scaling_factor[i] * lya_optical_depth[i] * lya_absorption[i];    /* :69 */
+    t1 += (K_inv_y[i] * da) * K_inv_y[i];
+    t2 += diag_K_inv[i] * da;
+    da = da * log(lya_1pz[i]) * beta;                                                 /* :73 */
+    b1 += (K_inv_y[i] * da) * K_inv_y[i];
+    b2 += diag_K_inv[i] * da;
+  }
+  *dlog_c_0 = -c1 + c2;   /* :66 */
+  *dlog_tau_0 = -t1 + t2; /* :70 */
+  *dlog_beta = -b1 + b2;  /* :74 */
+done:
+  free(lya_optical_depth); free(lya_absorption); free(scaling_factor); free(absorption_noise);
+  free(d); free(d_inv); free(D_inv_y); free(D_inv_M); free(B); free(R); free(C); free(Cy); free(CM);
+  free(K_inv_y); free(K_inv_M); free(diag_K_inv); free(yM);
+  return rc;
+}
+
+/* objective.m:12-75.  The three data matrices are [num_quasars x num_pixels] column-major with NaN
+ * marking missing pixels (:42); x = [vec M; log omega; log c0; log tau0; log beta] (:5). */
+int gpdla_oracle_objective(const double *x, int64_t num_quasars, int64_t num_pixels, int k,
+                           const double *centered_rest_fluxes, const double *lya_1pzs,
+                           const double *rest_noise_variances, int num_threads, double *f,
+                           double *g) {
+  const size_t G = (size_t)num_pixels;
+  const double *M = x, *log_omega = x + G * k;
+  const double log_c_0 = x[G * (k + 1)], log_tau_0 = x[G * (k + 1) + 1], log_beta = x[G * (k + 1) + 2];
+  const double c_0 = exp(log_c_0), tau_0 = exp(log_tau_0), beta = exp(log_beta); /* :30-32 */
+  double *omega2 = (double *)malloc(sizeof(double) * G);
+  for (size_t p = 0; p < G; p++) omega2[p] = exp(2 * log_omega[p]); /* :29 */
+  double fsum = 0.0, dc = 0.0, dt = 0.0, db = 0.0;
+  memset(g, 0, sizeof(double) * (G * (k + 1) + 3));
+  int fail = 0;
+#ifdef _OPENMP
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+#else
+  (void)num_threads;
+#endif
+#pragma omp parallel
+  {
+    double *y = (double *)malloc(sizeof(double) * G), *l1 = (double *)malloc(sizeof(double) * G);
+    double *nv = (double *)malloc(sizeof(double) * G), *om = (double *)malloc(sizeof(double) * G);
+    double *Mi = (double *)malloc(sizeof(double) * G * k), *dM = (double *)malloc(sizeof(double) * G * k);
+    double *dlo = (double *)malloc(sizeof(double) * G);
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * G);
+    double *gl = (double *)calloc(G * (k + 1) + 3, sizeof(double));
+    double fl = 0.0;
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t i = 0; i < num_quasars; i++) { /* :41 */
+      int64_t n = 0;
+      for (size_t p = 0; p < G; p++) {
+        double v = centered_rest_fluxes[i + p * num_quasars];
+        if (isnan(v)) continue; /* :42 */
+        idx[n] = (int64_t)p;
+        y[n] = v;
+        l1[n] = lya_1pzs[i + p * num_quasars];
+        nv[n] = rest_noise_variances[i + p * num_quasars];
+        om[n] = omega2[p];
+        n++;
+      }
+      if (n == 0) continue;
+      for (int a = 0; a < k; a++)
+        for (int64_t j = 0; j < n; j++) Mi[j + a * n] = M[idx[j] + a * G];
+      double tf, tc, tt, tb;
+      if (gpdla_oracle_spectrum_loss(y, l1, nv, Mi, om, n, k, c_0, tau_0, beta, &tf, dM, dlo, &tc,
+                                     &tt, &tb)) {
+#pragma omp atomic write
+        fail = 1;
+        continue;
+      }
+      fl += tf; /* :50-55 */
+      for (int a = 0; a < k; a++)
+        for (int64_t j = 0; j < n; j++) gl[idx[j] + a * G] += dM[j + a * n];
+      for (int64_t j = 0; j < n; j++) gl[G * k + idx[j]] += dlo[j];
+      gl[G * (k + 1)] += tc;
+      gl[G * (k + 1) + 1] += tt;
+      gl[G * (k + 1) + 2] += tb;
+    }
+#pragma omp critical
+    {
+      fsum += fl;
+      for (size_t e = 0; e < G * (k + 1); e++) g[e] += gl[e];
+      dc += gl[G * (k + 1)];
+      dt += gl[G * (k + 1) + 1];
+      db += gl[G * (k + 1) + 2];
+    }
+    free(y); free(l1); free(nv); free(om); free(Mi); free(dM); free(dlo); free(idx); free(gl);
+  }
+  /* priors of Kim et al. (2007), :59-71 (added to the gradient only, as the reference does) */
+  const double tau_0_mu = 0.0023, tau_0_sigma = 0.0007, beta_mu = 3.65, beta_sigma = 0.21;
+  dt += tau_0 * (tau_0 - tau_0_mu) / (tau_0_sigma * tau_0_sigma);
+  db += beta * (beta - beta_mu) / (beta_sigma * beta_sigma);
+  g[G * (k + 1)] = dc;
+  g[G * (k + 1) + 1] = dt;
+  g[G * (k + 1) + 2] = db;
+  *f = fsum;
+  free(omega2);
+  return fail ? -1 : 0;
+}

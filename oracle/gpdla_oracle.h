@@ -10,6 +10,7 @@
  *   log_mvnpdf_low_rank.m:5-34      (Woodbury low-rank Gaussian log-pdf, incl. the k x n matrix C)
  *   process_qsos.m:96-213           (per-spectrum driver: selection, interpolation, sweep, evidence)
  *   multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-477 (multi-DLA / LLS / mean-flux driver)
+ *   spectrum_loss.m:14-76, objective.m:12-75 (training objective and gradient, "next" row N3)
  *
  * Third-party arithmetic: voigt.c:288 calls libcerf's  double voigt(double x, double sigma,
  * double gamma)  (libcerf is NOT in /root/reference and its version is not pinned anywhere,
@@ -130,6 +131,20 @@ int gpdla_oracle_process_spectrum_multi(
     double *sample_log_likelihoods_dla, double *log_likelihoods_dla,
     double *sample_log_likelihoods_lls, double *log_likelihood_lls, double *MAP_z_dlas,
     double *MAP_log_nhis, double *MAP_inds);
+
+/* spectrum_loss.m:14-76 (row N3 of SURVEY.md section 8f).  M, dM: n x k column-major. */
+int gpdla_oracle_spectrum_loss(const double *y, const double *lya_1pz, const double *noise_variance,
+                               const double *M, const double *omega2, int64_t n, int k, double c_0,
+                               double tau_0, double beta, double *nlog_p, double *dM,
+                               double *dlog_omega, double *dlog_c_0, double *dlog_tau_0,
+                               double *dlog_beta);
+
+/* objective.m:12-75.  Data matrices [num_quasars x num_pixels] column-major, NaN = missing;
+ * x and g have num_pixels*(k+1) + 3 entries ([vec M; log omega; log c0; log tau0; log beta]). */
+int gpdla_oracle_objective(const double *x, int64_t num_quasars, int64_t num_pixels, int k,
+                           const double *centered_rest_fluxes, const double *lya_1pzs,
+                           const double *rest_noise_variances, int num_threads, double *f,
+                           double *g);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,9 @@ def load():
     lib.gpdla_oracle_process_spectrum_multi.argtypes = [
         C.POINTER(_Params), C.POINTER(_Model), C.POINTER(_Multi), C.c_int64, _dp, _dp, C.c_int64,
         _dp, _dp, _dp, _u8p, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.gpdla_oracle_objective.restype = C.c_int
+    lib.gpdla_oracle_objective.argtypes = [_dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _dp, C.c_int,
+                                           _dp, _dp]
     _lib = lib
     return lib
 
@@ -256,3 +259,24 @@ def process_spectrum_multi(model, offset_samples, nhi_samples, log_nhi_samples, 
                 log_likelihoods_dla=ll_dla, sample_log_likelihoods_lls=sll_lls,
                 log_likelihood_lls=ll_lls.value, MAP_z_dlas=np.array(mapz),
                 MAP_log_nhis=np.array(mapn), MAP_inds=np.array(mapi))
+
+
+def objective(x, centered_rest_fluxes, lya_1pzs, rest_noise_variances, num_threads=0):
+    """objective.m:12-75: (f, g) for x = [vec M; log omega; log c0; log tau0; log beta]; the data
+    matrices are (num_quasars, num_pixels) with NaN for missing pixels."""
+    lib = load()
+    F = np.asfortranarray(centered_rest_fluxes, dtype=np.float64)
+    Lz = np.asfortranarray(lya_1pzs, dtype=np.float64)
+    Nv = np.asfortranarray(rest_noise_variances, dtype=np.float64)
+    nq, G = F.shape
+    x, xp = _d(x)
+    k = (x.size - 3) // G - 1
+    assert x.size == G * (k + 1) + 3
+    f = C.c_double()
+    g = np.zeros_like(x)
+    rc = lib.gpdla_oracle_objective(xp, nq, G, k, F.ctypes.data_as(_dp), Lz.ctypes.data_as(_dp),
+                                    Nv.ctypes.data_as(_dp), int(num_threads), C.byref(f),
+                                    g.ctypes.data_as(_dp))
+    if rc:
+        raise ValueError("oracle objective: B not positive definite")
+    return f.value, g
