@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("GPDLA_LIB_PATH") or os.path.join(CSRC, "libgpdla.so")
 # process already loaded: PyTorch's bundled one under Python (preloaded below), `-lamdhip64` for a
 # C / MEX consumer.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
-               "-std=c++17", "-no-hip-rt"]
+               "-std=c++17", "-no-hip-rt", "-Wno-inline-asm"]
 
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     return is_null ? 1.0 : v;
   };
   double a_next = absorption(jj);  // step 0
-  __builtin_amdgcn_s_waitcnt(0);
+  glds_wait();
   __syncthreads();
   if (nchunks > 1) issue_chunk(1);
 
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     const int rn = t + 1;
     const int cn = rn / kChunkSteps;
     if (rn % kChunkSteps == 0) {
+      glds_wait();  // chunk cn (issued one chunk ago) has landed
       __syncthreads();
       if (cn + 1 < nchunks) issue_chunk(cn + 1);
     }

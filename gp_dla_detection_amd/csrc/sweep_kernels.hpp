@@ -452,10 +452,26 @@ __device__ __forceinline__ double wing_core(double x2, double y2) {
   return rho * t;
 }
 
+// Asynchronous global -> LDS copy, 16 bytes per lane (lane l lands at lds_wave_base + 16 l).
+// Issued as inline assembly on purpose: with __builtin_amdgcn_global_load_lds the compiler cannot
+// tell which LDS bytes the DMA writes and puts s_waitcnt vmcnt(0) in front of EVERY later LDS read,
+// i.e. the first K-step of a chunk waits for the prefetch of the next one (measured: 20 % of the
+// sweep).  The kernels order these copies themselves: glds_wait() + __syncthreads() before a stage
+// buffer is read, and a barrier after its last read before it is refilled.
 __device__ __forceinline__ void glds16(const double *gsrc, double *lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(
-      (const __attribute__((address_space(1))) void *)gsrc,
-      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+  const uint32_t lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(gsrc), "s"(lds)
+               : "memory", "m0");
+}
+// s_waitcnt vmcnt(0) only (gfx9 encoding: expcnt and lgkmcnt fields at their maxima).  The builtin,
+// not inline assembly: the compiler's own wait-count bookkeeping sees it and keeps its
+// conservative vmcnt waits out of the loops that follow.
+__device__ __forceinline__ void glds_wait() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" ::: "memory");
 }
 
 // Epilogue shared by the sweep kernels: one round (MFMA result register r) of the per-sample
@@ -711,7 +727,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   const double tap0 = g_lines.taps[0], tap1 = g_lines.taps[1], tap2 = g_lines.taps[2],
                tap3 = g_lines.taps[3];
 
-  __builtin_amdgcn_s_waitcnt(0);  // chunk 0 landed (vmcnt(0))
+  glds_wait();  // chunk 0 landed
   __syncthreads();
 
   // The fp64 MFMA does not overlap with VALU work on its SIMD (tools/fp64_mix_probe.hip), so the
@@ -719,9 +735,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   // value three steps ahead (wing tier branch-free; accurate tier under a wave-uniform vote), the
   // 7-tap broadening from the doubled ring (no wrap-around: slots are compile-time), the weights,
   // then 16 MFMAs.  Two waves per SIMD hide LDS and dependent-issue latency.
+  // Per K-step: all LDS operands (7 ring taps, pixel row, 16 B fragments) are requested first and
+  // land while the raw-profile VALU chain runs; the only read that chain itself needs, the padded
+  // wavelength, is fetched one step early (within a chunk), before the previous MFMA burst.
   for (int c = 0; c < nchunks; ++c) {
+    // Nothing of ours is in flight here (drained before the barrier), so this wait is free; it is
+    // for the compiler, whose scratch reloads of the loop preheader would otherwise be waited for
+    // inside the K-steps -- behind the prefetch issued on the next line.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (c + 1 < nchunks) issue_chunk(c + 1);  // lands in the other buffer while we compute
     const double *buf = stage + (size_t)(c & 1) * kChunkSteps * RD;
+    double lam_next = 0.0;
 #pragma unroll
     for (int tt = 0; tt < kChunkSteps; ++tt) {
       const int rn = c * kChunkSteps + tt;
@@ -731,8 +755,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         // ring slot of pixel 4 rn (+ jj, folded into my_ring); compile-time when chunks are 4 long
         const int slot_p = kChunkSteps == 4 ? 4 * tt : ((4 * rn) & 15);
         const int slot_w = (slot_p + 12) & 15;
+        // lam_next was requested before the previous MFMA burst and has long landed: saying so
+        // (s_waitcnt lgkmcnt(0), free) lets the raw chain start under the 15 reads issued next
+        // instead of behind all of them.
+        if (tt > 0) __builtin_amdgcn_s_waitcnt(0xC07F);
+        const double lamP = tt == 0 ? extra[16 + jj] : lam_next;
+        // operands of the broadening / weights / MFMAs of this step
+        const double *g = my_ring + slot_p;
+        const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4], g5 = g[5], g6 = g[6];
+        const double py = extra[4 * jj], pmu = extra[4 * jj + 1], pom = extra[4 * jj + 2],
+                     pnu = extra[4 * jj + 3];
+        const T *bt = reinterpret_cast<const T *>(rec) + (size_t)tile0 * 64 + lane;
+        T bop[NTW];
+#pragma unroll
+        for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads up here (the scheduler sinks them)
         // (1) raw profile three K-steps ahead: voigt.c:282-292
-        const double lamP = extra[16 + jj];
         double total;
         bool near;
         if (LINES == 3) {
@@ -749,30 +787,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         }
         double raw = exp_table(nscale * total, exp_tab);
 #ifndef GPDLA_ABLATE_NOSLOW
-        if (__builtin_expect(__any(near), 0)) raw = GPDLA_RAW_ACCURATE(lamP);
+        if (__builtin_expect(__any(near), 0)) {
+          raw = GPDLA_RAW_ACCURATE(lamP);
+          // The registers the call clobbers come back from scratch right after it; draining vmcnt
+          // HERE keeps those reloads from turning into s_waitcnt vmcnt(0) at the top of every
+          // K-step, where they would wait for the in-flight chunk prefetch instead.
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
 #endif
 #ifdef GPDLA_ABLATE_NOVOIGT
         raw = lamP * 1e-4;
 #endif
         my_ring[slot_w] = raw;
         my_ring[slot_w + 16] = raw;
-        // B fragments of this step: requested now, consumed by the MFMAs after the weights
-        const T *bt = reinterpret_cast<const T *>(rec) + (size_t)tile0 * 64 + lane;
-        T bop[NTW];
-#pragma unroll
-        for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
-        __builtin_amdgcn_sched_barrier(0);  // keep the reads up here (the scheduler sinks them)
         // (2) instrument broadening for pixel 4 rn + jj: voigt.c:297-299 (symmetric taps)
-        const double *g = my_ring + slot_p;
-        double absorb = fma(g[6], tap0, g[0] * tap0);
-        double ab2 = fma(g[5], tap1, g[1] * tap1);
-        absorb = fma(g[2], tap2, absorb);
-        ab2 = fma(g[4], tap2, ab2);
-        absorb = fma(g[3], tap3, absorb) + ab2;
+        double absorb = fma(g6, tap0, g0 * tap0);
+        double ab2 = fma(g5, tap1, g1 * tap1);
+        absorb = fma(g2, tap2, absorb);
+        ab2 = fma(g4, tap2, ab2);
+        absorb = fma(g3, tap3, absorb) + ab2;
         if (is_null) absorb = 1.0;
         // (3) weights: process_qsos.m:192-198 folded into log_mvnpdf_low_rank.m:11-15
-        const double py = extra[4 * jj], pmu = extra[4 * jj + 1], pom = extra[4 * jj + 2],
-                     pnu = extra[4 * jj + 3];
         const double r = fma(-absorb, pmu, py);
         const double a2 = absorb * absorb;
         const double d = fma(pom, a2, pnu);
@@ -783,6 +818,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         dprod *= d;  // Sum log d as the log of a running product, renormalised every step
         dexp += __builtin_amdgcn_frexp_exp(dprod);
         dprod = __builtin_amdgcn_frexp_mant(dprod);
+        // next step's wavelength, in flight during the MFMA burst
+        if (tt + 1 < kChunkSteps) {
+          lam_next = extra[RD + 16 + jj];
+          __builtin_amdgcn_sched_barrier(0);
+        }
         // (4) rank-4 update of [B | v] on the matrix cores
 #ifdef GPDLA_ABLATE_NOMFMA
 #pragma unroll
@@ -800,7 +840,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #ifdef GPDLA_ABLATE_NOBARRIER
     __builtin_amdgcn_s_waitcnt(0);  // timing experiment only: races on the stage buffers
 #else
-    __syncthreads();  // (waits vmcnt(0) for the prefetched chunk first)
+    glds_wait();  // the prefetched chunk has landed (this wave's part) ...
+    __syncthreads();  // ... and everyone's; all reads of the buffer refilled next are done
 #endif
   }
 #undef GPDLA_RAW_ACCURATE

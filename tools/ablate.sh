@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 SRC=gp_dla_detection_amd/csrc/gpdla.hip
-FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt"
+FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -Wno-inline-asm"
 mkdir -p gpurun_out /tmp/ablate
 : > gpurun_out/ablate.txt
 for v in BASE NOBARRIER NOSLOW NOEPI NOVOIGT NOMFMA "NOSLOW -DGPDLA_ABLATE_NOEPI" "NOSLOW -DGPDLA_ABLATE_NOEPI -DGPDLA_ABLATE_NOVOIGT" "NOSLOW -DGPDLA_ABLATE_NOEPI -DGPDLA_ABLATE_NOMFMA"; do
