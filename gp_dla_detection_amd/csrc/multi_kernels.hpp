@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     const double q_s = __shfl(quad_sum, src_lane);
     const double ld_s = __shfl(logd_sum, src_lane);
     const int64_t slot_s = slot0 + jj + 4 * r;
-    const double ll = factor_round<NTW, TS, TW, 0>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
+    const double ll = factor_round<NTW, TS, TW>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
                                                    q_s, ld_s, m.n_kept);
     if (role == 0 && s == 0) {
       if (slot_s < a.S) {

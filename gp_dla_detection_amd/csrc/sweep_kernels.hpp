@@ -476,64 +476,89 @@ __device__ __forceinline__ void glds_wait() {
 
 // Epilogue shared by the sweep kernels: one round (MFMA result register r) of the per-sample
 // factorisation.  The 16 lanes of row jj hold, in register r of every tile, the 16*NT columns of
-// sample jj + 4r: they spill them to LDS (e = [16*NT] doubles for this row) and factor the augmented
-// (k+1) x (k+1) matrix [[I + B, v], [v', .]] column by column, lane s taking rows j+1+s, j+1+s+16
-// of column j.  Row k of the augmented matrix is v, so its factor row is z = L^-1 v.
-// Returns log N(y; a mu, ...) of that sample (log_mvnpdf_low_rank.m:30-32) in every lane of the row
-// (meaningful for role 0 only).  q_s = Sum r^2/d, ld_s = Sum log d of the sample.
-// One column of the factorisation: diagonal, then this lane's rows below it.
-__device__ __forceinline__ void factor_column(double *e, int j, int k, int s, int voff,
-                                              double &lprod, double &zz, bool &pd) {
-  const int rj = j * (j + 1) / 2;
-  double dj = e[rj + j] + 1.0;  // log_mvnpdf_low_rank.m:22-23
-  for (int mm = 0; mm < j; ++mm) {
-    const double t = e[rj + mm];
-    dj = fma(-t, t, dj);
-  }
-  pd = pd && (dj > 0.0);
-  const double ljj = sqrt(dj);  // :24
-  const double inv = 1.0 / ljj;
-  lprod *= ljj;
-  for (int i = j + 1 + s; i <= k; i += 16) {
-    const int ri = (i < k) ? i * (i + 1) / 2 : voff;
-    double t = e[ri + j];
-    for (int mm = 0; mm < j; ++mm) t = fma(-e[ri + mm], e[rj + mm], t);
-    t *= inv;
-    e[ri + j] = t;
-    if (i == k) zz = fma(t, t, zz);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+// sample jj + 4r: they spill them to LDS (e = [16*NT] doubles for this row: packed lower triangle
+// of B, then v at voff) and factor the augmented (k+1) x (k+1) matrix [[I + B, v], [v', .]] column
+// by column (left-looking).  Row k of the augmented matrix is v, so its factor row is z = L^-1 v.
+//
+// Lane s of the 16 owns rows s, s+16 (, s+32) for the whole factorisation and keeps their running
+// diagonals  dd_i = A_ii - Sum_{m<j} l_im^2  in registers.  Column j then needs no dot product for
+// its pivot: the owner of row j broadcasts dd_j, every lane takes ONE reciprocal square root
+// (v_rsq_f64 + two Newton steps: no sqrt, no division, :24 is only ever used through 1/L_jj and
+// log L_jj = log(d_j)/2), and the row dot products -- which do not depend on the pivot -- run
+// alongside.  -dd of row k ends as z'z.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);  // ~2^-26
+  const double h = 0.5 * x;
+  double err = fma(-h * y, y, 0.5);
+  y = fma(y, err, y);
+  err = fma(-h * y, y, 0.5);
+  return fma(y, err, y);
 }
 
-// The factorisation proper, on one sample's columns already in LDS.
-// KC: k when known at compile time (the column loop is then fully unrolled, which lets the
-// compiler batch the LDS reads of each dot product), 0 for a run-time k.
-template <int KC>
+// The factorisation proper, on one sample's columns already in LDS.  ROWS = ceil((k+1)/16) rows
+// per lane at most.  Returns log N(y; a mu, ...) of that sample (log_mvnpdf_low_rank.m:30-32) in
+// every lane of the row.  q_s = Sum r^2/d, ld_s = Sum log d of the sample.
+template <int ROWS>
 __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, double q_s, double ld_s,
                                           int n_kept) {
-  double lprod = 1.0, zz = 0.0;
-  bool pd = true;
-  if (KC > 0) {
+  int ro[ROWS];
+  double dd[ROWS];
 #pragma unroll
-    for (int j = 0; j < KC; ++j) factor_column(e, j, KC, s, voff, lprod, zz, pd);
-  } else {
-    for (int j = 0; j < k; ++j) factor_column(e, j, k, s, voff, lprod, zz, pd);
+  for (int a = 0; a < ROWS; ++a) {
+    const int i = s + 16 * a;
+    ro[a] = i < k ? i * (i + 1) / 2 : voff;        // rows beyond k alias v and are never written
+    dd[a] = i < k ? e[ro[a] + i] + 1.0 : 0.0;      // log_mvnpdf_low_rank.m:22-23
   }
-  zz += __shfl_xor(zz, 1);
-  zz += __shfl_xor(zz, 2);
-  zz += __shfl_xor(zz, 4);
-  zz += __shfl_xor(zz, 8);
-  const double log_det = ld_s + 2 * log(lprod);  // log_mvnpdf_low_rank.m:30
-  const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);  // :32
+  double lprod = 1.0;
+  int lexp = 0;
+  bool pd = true;
+  for (int j = 0; j < k; ++j) {
+    const int rj = j * (j + 1) / 2;
+    double dsel = dd[0];
+    if (ROWS > 1 && j >= 16) dsel = dd[1];
+    if (ROWS > 2 && j >= 32) dsel = dd[ROWS > 2 ? 2 : 0];
+    const double dj = __shfl(dsel, j & 15, 16);    // pivot, from the lane that owns row j
+    double t[ROWS];
+#pragma unroll
+    for (int a = 0; a < ROWS; ++a) t[a] = e[ro[a] + j];
+#pragma unroll 4
+    for (int mm = 0; mm < j; ++mm) {
+      const double c = e[rj + mm];
+#pragma unroll
+      for (int a = 0; a < ROWS; ++a) t[a] = fma(-e[ro[a] + mm], c, t[a]);
+    }
+    pd = pd && (dj > 0.0);                         // chol would throw here (:24)
+    const double inv = rsqrt_nr(dj);
+    lprod *= dj;                                   // 2 Sum log L_jj = log Prod d_j (:30)
+    lexp += __builtin_amdgcn_frexp_exp(lprod);
+    lprod = __builtin_amdgcn_frexp_mant(lprod);
+#pragma unroll
+    for (int a = 0; a < ROWS; ++a) {
+      const int i = s + 16 * a;
+      t[a] *= inv;
+      if (i > j && i <= k) {
+        e[ro[a] + j] = t[a];
+        dd[a] = fma(-t[a], t[a], dd[a]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  double zsel = dd[0];
+  if (ROWS > 1 && k >= 16) zsel = dd[1];
+  if (ROWS > 2 && k >= 32) zsel = dd[ROWS > 2 ? 2 : 0];
+  const double zz = -__shfl(zsel, k & 15, 16);     // z'z with z = L^-1 v
+  const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
+  const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32
   return pd ? ll : NAN;
 }
 
-template <int NTW, int TS, int TW, int KC, typename ACC>
+template <int NTW, int TS, int TW, typename ACC>
 __device__ __forceinline__ double factor_round(const ACC (&acc)[NTW], int r, double *e, int s,
                                                int role, int tile0, int k, double q_s, double ld_s,
                                                int n_kept) {
   constexpr int voff = TW * 16;
+  constexpr int ROWS = TW > 30 ? 3 : 2;  // TW = 14: k <= 20 (rows 0..20); TW = 52: k <= 40
   if (TS > 1) __syncthreads();
 #pragma unroll
   for (int cc = 0; cc < NTW; ++cc) e[(tile0 + cc) * 16 + s] = (double)acc[cc][r];
@@ -545,7 +570,7 @@ __device__ __forceinline__ double factor_round(const ACC (&acc)[NTW], int r, dou
 #ifdef GPDLA_ABLATE_NOEPI
   return q_s + ld_s + e[0];
 #else
-  return role == 0 ? factor_lds<KC>(e, s, k, voff, q_s, ld_s, n_kept) : NAN;
+  return role == 0 ? factor_lds<ROWS>(e, s, k, voff, q_s, ld_s, n_kept) : NAN;
 #endif
 }
 
@@ -866,7 +891,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
     const double ld_s = __shfl(logd_sum, src_lane);
     const int64_t slot_s = slot0 + sigma;
     const int32_t sample_s = __shfl(sample, src_lane);
-    const double ll = factor_round<NTW, TS, TW, 0>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
+    const double ll = factor_round<NTW, TS, TW>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
                                                    q_s, ld_s, m.n_kept);
     if (role == 0 && s == 0) {
       if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
