@@ -790,10 +790,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4], g5 = g[5], g6 = g[6];
         const double py = extra[4 * jj], pmu = extra[4 * jj + 1], pom = extra[4 * jj + 2],
                      pnu = extra[4 * jj + 3];
-        const T *bt = reinterpret_cast<const T *>(rec) + (size_t)tile0 * 64 + lane;
-        T bop[NTW];
-#pragma unroll
-        for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
         __builtin_amdgcn_sched_barrier(0);  // keep the reads up here (the scheduler sinks them)
         // (1) raw profile three K-steps ahead: voigt.c:282-292
         double total;
@@ -823,6 +819,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #ifdef GPDLA_ABLATE_NOVOIGT
         raw = lamP * 1e-4;
 #endif
+        // B fragments of this step: requested only now, so that they are not live across the
+        // accurate-tier call above (which would park accumulators in scratch to make room); they
+        // land during the broadening and weight arithmetic.
+        const T *bt = reinterpret_cast<const T *>(rec) + (size_t)tile0 * 64 + lane;
+        T bop[NTW];
+#pragma unroll
+        for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
+        __builtin_amdgcn_sched_barrier(0);
         my_ring[slot_w] = raw;
         my_ring[slot_w + 16] = raw;
         // (2) instrument broadening for pixel 4 rn + jj: voigt.c:297-299 (symmetric taps)

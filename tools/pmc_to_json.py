@@ -1,0 +1,42 @@
+"""Merge the rocprofv3 --pmc passes of tools/profile.sh into one JSON summary for k_sweep.
+
+usage: pmc_to_json.py <gpurun_out dir> <tag>
+FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB (rocprofv3 derived counters); FETCH_SIZE is
+doubled for gfx950 (MI355X_MICROARCH.md, HBM section: wide coalesced streaming reads are reported at
+half their bytes); WRITE_SIZE is taken as read.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    counters, launches, kernel = {}, {}, None
+    for path in glob.glob(os.path.join(out, f"pmc_{tag}_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if "k_sweep" not in row["Kernel_Name"]:
+                    continue
+                kernel = row["Kernel_Name"]
+                c = row["Counter_Name"]
+                counters[c] = counters.get(c, 0.0) + float(row["Counter_Value"])
+                launches[c] = launches.get(c, 0) + 1
+    per_launch = {c: counters[c] / launches[c] for c in sorted(counters)}
+    # tools/profile.sh runs bench.py with its defaults: BASELINE configs[1]
+    res = {"kernel": kernel,
+           "config": {"spectra": 1000, "pixels": 1500, "k": 20, "dla_samples": 10000, "num_lines": 3}, "launches_per_counter": launches, "counters_per_launch": per_launch,
+           "note": "separate --pmc passes (tools/profile.sh); FETCH_SIZE doubled for gfx950, WRITE_SIZE as read; "
+                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in "
+                   "cycles, GRBM_GUI_ACTIVE summed over the 8 XCDs"}
+    if "FETCH_SIZE" in per_launch and "WRITE_SIZE" in per_launch:
+        res["fetch_size_kb"] = per_launch["FETCH_SIZE"]
+        res["write_size_kb"] = per_launch["WRITE_SIZE"]
+        res["hbm_bytes_per_launch"] = (2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024.0
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
