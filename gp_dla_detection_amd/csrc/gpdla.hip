@@ -1085,3 +1085,14 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
 }
 
 }  // extern "C"
+
+#ifdef GPDLA_STAMP
+// Diagnostic build only (tools/stamps.sh): read and clear the per-segment wave-cycle sums.
+extern "C" int gpdla_debug_stamps(unsigned long long *out) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpdla::g_stamps), sizeof(zero)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(gpdla::g_stamps), zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

@@ -644,6 +644,24 @@ __device__ __forceinline__ double exp_table(double x, const double *tab) {
   return ldexp(tab[ni & (kExpTab - 1)] * p, ni >> 6);
 }
 
+// Diagnostic build only (-DGPDLA_STAMP, tools/stamps.sh): s_memtime brackets around the segments of
+// a K-step, summed per wave in scalar registers and added to g_stamps once per wave.  The stamp
+// drains lgkmcnt, so it forbids overlaps the real kernel has: read SHARES, never the run time.
+#ifdef GPDLA_STAMP
+__device__ unsigned long long g_stamps[8];
+#define GPDLA_ST(i)                                                                     \
+  {                                                                                     \
+    unsigned long long t_;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    st_sum[i] += (uint32_t)t_ - st_prev; /* a wave's whole sweep is < 2^32 cycles */    \
+    st_prev = (uint32_t)t_;                                                             \
+  }
+#else
+#define GPDLA_ST(i)
+#endif
+
 // Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk
 // (must be 4: the step loop is unrolled over the chunk so ring slots are compile-time),
 // TW tiles that take the weight w (the rest take u; TS*NTW tiles in all, zero-padded), LINES
@@ -763,12 +781,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   // Per K-step: all LDS operands (7 ring taps, pixel row, 16 B fragments) are requested first and
   // land while the raw-profile VALU chain runs; the only read that chain itself needs, the padded
   // wavelength, is fetched one step early (within a chunk), before the previous MFMA burst.
+#ifdef GPDLA_STAMP
+  uint32_t st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  {
+    unsigned long long t0_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0_)::"memory");
+    st_prev = (uint32_t)t0_;
+  }
+#endif
   for (int c = 0; c < nchunks; ++c) {
     // Nothing of ours is in flight here (drained before the barrier), so this wait is free; it is
     // for the compiler, whose scratch reloads of the loop preheader would otherwise be waited for
     // inside the K-steps -- behind the prefetch issued on the next line.
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    GPDLA_ST(4)  // chunk-end drain + barrier
     if (c + 1 < nchunks) issue_chunk(c + 1);  // lands in the other buffer while we compute
+    GPDLA_ST(5)  // prefetch issue
     const double *buf = stage + (size_t)(c & 1) * kChunkSteps * RD;
     double lam_next = 0.0;
 #pragma unroll
@@ -807,6 +835,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
           }
         }
         double raw = exp_table(nscale * total, exp_tab);
+        GPDLA_ST(0)  // operand requests + wing-tier raw profile
 #ifndef GPDLA_ABLATE_NOSLOW
         if (__builtin_expect(__any(near), 0)) {
           raw = GPDLA_RAW_ACCURATE(lamP);
@@ -816,6 +845,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
           __builtin_amdgcn_s_waitcnt(0x0F70);
         }
 #endif
+        GPDLA_ST(1)  // accurate tier
 #ifdef GPDLA_ABLATE_NOVOIGT
         raw = lamP * 1e-4;
 #endif
@@ -852,6 +882,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
           lam_next = extra[RD + 16 + jj];
           __builtin_amdgcn_sched_barrier(0);
         }
+        GPDLA_ST(2)  // fragments, ring, broadening, weights
         // (4) rank-4 update of [B | v] on the matrix cores
 #ifdef GPDLA_ABLATE_NOMFMA
 #pragma unroll
@@ -864,6 +895,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         for (int cc = 0; cc < NTW; ++cc)
           acc[cc] = Mat<T>::mfma((T)(cc < nw ? w : u), bop[cc], acc[cc]);
 #endif
+        GPDLA_ST(3)  // MFMA burst (issue)
       }
     }
 #ifdef GPDLA_ABLATE_NOBARRIER
@@ -902,6 +934,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
       else if (slot_s == a.S) a.ll_no_dla[q] = ll;
     }
   }
+#ifdef GPDLA_STAMP
+  GPDLA_ST(6)  // epilogue (after the last chunk barrier)
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], (unsigned long long)st_sum[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
