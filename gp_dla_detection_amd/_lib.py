@@ -111,6 +111,7 @@ SYMBOLS = [
                                         C.POINTER(C.c_void_p)]),
     ("gpdla_training_objective", C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
     ("gpdla_training_destroy", None, [C.c_void_p]),
+    ("gpdla_debug_near_poly", C.c_int, [C.c_int, C.c_double, _dp, _dp]),
 ]
 
 _lib = None

@@ -58,10 +58,30 @@ int select_device(int device_id) {
 std::mutex g_table_mutex;
 bool g_table_loaded[64] = {false};
 
+// Damping parameters y_j = gamma_j / (sqrt2 sigma) and the accurate-tier polynomial tables built from
+// them (near_tables.hpp); host copy, built once per process.
+std::vector<double> g_near_host;
+double g_line_y[kMaxLines];
+
+void ensure_near_host() {  // caller holds g_table_mutex
+  if (!g_near_host.empty()) return;
+#define GP_GAM0(i, wl, f, G, lead, gam) gam,
+  const double gam[] = {GPDLA_LYMAN_SERIES(GP_GAM0)};
+#undef GP_GAM0
+  const double sigma = GPDLA_GAUSS_SIGMA_CGS;
+  for (int i = 0; i < kMaxLines; ++i) g_line_y[i] = gam[i] / std::sqrt(2.0) / sigma;
+  build_near_tables(g_line_y, kMaxLines, g_near_host);
+}
+
 int ensure_line_table(int device_id) {
   std::lock_guard<std::mutex> lock(g_table_mutex);
   if (device_id < 64 && g_table_loaded[device_id]) return GPDLA_OK;
+  ensure_near_host();
+  double *d_near = nullptr;  // lives as long as the process (one per device)
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_near), g_near_host.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(d_near, g_near_host.data(), g_near_host.size() * sizeof(double), hipMemcpyHostToDevice));
   LineTable t;
+  t.near_poly = d_near;
 #define GP_WL(i, wl, f, G, lead, gam) wl,
 #define GP_LEAD(i, wl, f, G, lead, gam) lead,
 #define GP_GAM(i, wl, f, G, lead, gam) gam,
@@ -1085,6 +1105,21 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
 }
 
 }  // extern "C"
+
+// Host evaluation of the accurate-tier table of one Lyman line (0-based) at |x| < 32: what the sweep
+// kernel computes for Re w(x + i y_line).  Needs no GPU; tests/test_near_tables.py checks it
+// against mpmath.  *y_out (optional) receives the line's damping parameter.
+extern "C" int gpdla_debug_near_poly(int line, double x, double *value_out, double *y_out) {
+  if (line < 0 || line >= kMaxLines || !value_out || !(std::fabs(x) < 32.0))
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "gpdla_debug_near_poly: line %d, x %g", line, x);
+  {
+    std::lock_guard<std::mutex> lock(g_table_mutex);
+    ensure_near_host();
+  }
+  *value_out = near_poly_host(g_near_host.data() + (size_t)line * kNearLineDoubles, std::fabs(x));
+  if (y_out) *y_out = g_line_y[line];
+  return GPDLA_OK;
+}
 
 #ifdef GPDLA_STAMP
 // Diagnostic build only (tools/stamps.sh): read and clear the per-segment wave-cycle sums.

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "faddeeva.hpp"
+#include "near_tables.hpp"
 
 namespace gpdla {
 
@@ -71,6 +72,7 @@ struct LineTable {
   double c;                         // voigt.c:22
   double inv_sqrt2_sigma;           // 1/(sqrt2 sigma)
   double inv_sqrt2pi_sigma;         // 1/(sqrt(2 pi) sigma)
+  const double *near_poly;          // [31][kNearIntervals][kNearCoef], near_tables.hpp (device memory)
 };
 __constant__ LineTable g_lines;
 
@@ -574,27 +576,21 @@ __device__ __forceinline__ double factor_round(const ACC (&acc)[NTW], int r, dou
 #endif
 }
 
-// Accurate tier of the raw profile, out of line on purpose: it runs for ~5 % of the K-steps, and
-// inlining its register footprint into the pipelined main loop spills the accumulators.
-template <int LINES>
-__device__ __noinline__ double raw_accurate(double lamP, double m0, double m1, double m2,
-                                            const double *mult_lds, int L, double nscale) {
-  const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
-  double total = 0.0;
-  if (LINES > 0) {
-    const double mm[3] = {m0, m1, m2};
+// Accurate tier of the raw profile: Re w(|x| + i y_j) for |x| < 32 from line j's piecewise
+// polynomial (near_tables.hpp; same index arithmetic and Horner order as near_poly_host).
+__device__ __forceinline__ double near_poly(const double *line_tab, double ax) {
+  const bool core = ax < 8.0;
+  const double u = core ? ax * 8.0 : (ax - 8.0) * 2.0;
+  const int i = (int)u;
+  const double t = (u - (double)i) - 0.5;
+  const double *c = line_tab + (size_t)((core ? 0 : kNearCore) + i) * kNearCoef;
+  double cf[kNearCoef];
 #pragma unroll
-    for (int j = 0; j < (LINES > 0 ? LINES : 1); ++j) {
-      const double velocity = lamP * mm[j < 3 ? j : 0] - c_light;  // voigt.c:287
-      total = fma(g_lines.leading[j], rew_full(velocity * inv_s, g_lines.y[j]), total);
-    }
-  } else {
-    for (int j = 0; j < L; ++j) {
-      const double velocity = lamP * mult_lds[j] - c_light;
-      total = fma(g_lines.leading[j], rew_full(velocity * inv_s, g_lines.y[j]), total);
-    }
-  }
-  return exp_nonpos(nscale * 1.7724538509055159 * total);  // voigt.c:291
+  for (int k = 0; k < kNearCoef; ++k) cf[k] = c[k];  // 12 independent loads, then the Horner chain
+  double p = cf[kNearCoef - 1];
+#pragma unroll
+  for (int k = kNearCoef - 2; k >= 0; --k) p = fma(p, t, cf[k]);
+  return p;
 }
 
 // Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk,
@@ -642,6 +638,38 @@ __device__ __forceinline__ double exp_table(double x, const double *tab) {
   p = fma(p, r, 1.0);
   p = fma(p, r, 1.0);
   return ldexp(tab[ni & (kExpTab - 1)] * p, ni >> 6);
+}
+
+// Raw profile value where some line is within 30 Doppler widths (voigt.c:282-291, reference
+// two-rounding velocity): per line either the piecewise polynomial or the wing formula, a few
+// dozen instructions inline -- no call, no divergent trapezoid sums.
+template <int LINES>
+__device__ __forceinline__ double raw_near(double lamP, double m0, double m1, double m2,
+                                           const double *mult_lds, int L, double nscale,
+                                           const double *exp_tab) {
+  const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
+  const double *tab = g_lines.near_poly;
+  double total = 0.0;  // sqrt(pi) Sum_j lead_j Re w_j, the convention of the wing tier
+  if (LINES > 0) {
+    const double mm[3] = {m0, m1, m2};
+#pragma unroll
+    for (int j = 0; j < (LINES > 0 ? LINES : 1); ++j) {
+      const double ax = fabs((lamP * mm[j < 3 ? j : 0] - c_light) * inv_s);  // voigt.c:287
+      const double f = ax < 30.0
+                           ? 1.7724538509055159 * g_lines.leading[j] * near_poly(tab + j * kNearLineDoubles, ax)
+                           : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
+      total += f;
+    }
+  } else {
+    for (int j = 0; j < L; ++j) {
+      const double ax = fabs((lamP * mult_lds[j] - c_light) * inv_s);
+      const double f = ax < 30.0
+                           ? 1.7724538509055159 * g_lines.leading[j] * near_poly(tab + j * kNearLineDoubles, ax)
+                           : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
+      total += f;
+    }
+  }
+  return exp_table(nscale * total, exp_tab);
 }
 
 // Diagnostic build only (-DGPDLA_STAMP, tools/stamps.sh): s_memtime brackets around the segments of
@@ -739,9 +767,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
   for (int j = 0; j < (LINES > 0 ? LINES : 0); ++j) ms_r[j] = mult_r[j] * inv_s;
   const double cs = c_light * inv_s;
-#define GPDLA_RAW_ACCURATE(lamP)                                                            \
-  raw_accurate<LINES>((lamP), mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], \
-                      my_mult, L, nscale)
+#define GPDLA_RAW_ACCURATE(lamP)                                                        \
+  raw_near<LINES>((lamP), mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], \
+                  my_mult, L, nscale, exp_tab)
 
   __syncthreads();  // multipliers and the exp table visible
   // prime the ring with padded pixels 0..11 (the raw profile runs three K-steps ahead)
@@ -837,13 +865,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         double raw = exp_table(nscale * total, exp_tab);
         GPDLA_ST(0)  // operand requests + wing-tier raw profile
 #ifndef GPDLA_ABLATE_NOSLOW
-        if (__builtin_expect(__any(near), 0)) {
-          raw = GPDLA_RAW_ACCURATE(lamP);
-          // The registers the call clobbers come back from scratch right after it; draining vmcnt
-          // HERE keeps those reloads from turning into s_waitcnt vmcnt(0) at the top of every
-          // K-step, where they would wait for the in-flight chunk prefetch instead.
-          __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
+        if (__builtin_expect(__any(near), 0)) raw = GPDLA_RAW_ACCURATE(lamP);
 #endif
         GPDLA_ST(1)  // accurate tier
 #ifdef GPDLA_ABLATE_NOVOIGT

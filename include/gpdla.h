@@ -242,6 +242,15 @@ int gpdla_training_create(int device_id, int64_t num_quasars, int64_t num_pixels
 int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *f, double *g);
 void gpdla_training_destroy(gpdla_training *t);
 
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics.  The sweep kernel evaluates the Voigt function within 30 Doppler widths of a line
+ * centre from per-line piecewise polynomials of Re w(x + i y_line) (what voigt.c:288 gets from
+ * libcerf's voigt()).  This returns the HOST evaluation of the table of Lyman line `line`
+ * (0 = Ly-alpha) at |x| < 32, and the line's damping parameter y = gamma/(sqrt2 sigma) in *y_out
+ * (may be NULL).  Needs no GPU.
+ * ------------------------------------------------------------------------------------------- */
+int gpdla_debug_near_poly(int line, double x, double *value_out, double *y_out);
+
 #ifdef __cplusplus
 }
 #endif
