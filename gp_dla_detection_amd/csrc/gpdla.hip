@@ -447,7 +447,7 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   const int L = args.num_lines;
   const size_t RD = (size_t)record_doubles(b->ntiles, sizeof(T) == 4);
   const size_t stage_doubles = 2 * (size_t)CH * RD;
-  const size_t epi_doubles = (size_t)groups * 4 * b->ntiles * 16;
+  const size_t epi_doubles = (size_t)groups * EpilogueShape<TW>::SPP * EpilogueShape<TW>::stride(b->ntiles);
   // the epilogue reuses the whole dynamic array (stage buffers, then rings etc.: all dead by then)
   const size_t loop_doubles = stage_doubles + (size_t)WAVES * kSamplesPerWave * kRing2 + kExpTab +
                               (size_t)groups * kSamplesPerWave * L;
@@ -738,7 +738,10 @@ template <int NTW, int TS, int CH, int TW>
 int launch_sweep_multi(gpdla_context *c, gpdla_batch *b, SweepMultiArgs args) {
   constexpr int groups = kSweepWaves / TS;
   const size_t RD = (size_t)b->ntiles * 64 + 32;
-  const size_t lds = 2 * (size_t)CH * RD * sizeof(double);
+  // stage buffers during the loop; the epilogue reuses the array for its factorisation rows
+  const size_t lds = std::max(2 * (size_t)CH * RD,
+                              (size_t)groups * EpilogueShape<TW>::SPP * EpilogueShape<TW>::stride(b->ntiles)) * sizeof(double);
+  if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "multi sweep needs %zu B of LDS", lds);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_multi<NTW, TS, CH, TW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   args.blocks_per_quasar = (int32_t)((args.S + 1 + groups * kSamplesPerWave - 1) / (groups * kSamplesPerWave));

@@ -220,17 +220,16 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   logd_sum += __shfl_xor(logd_sum, 16);
   logd_sum += __shfl_xor(logd_sum, 32);
 
-  constexpr int ncols = NT * 16;
-  double *Eg = stage + (size_t)group * 4 * ncols;
+  using ES = EpilogueShape<TW>;
+  double *Eg = stage + (size_t)group * ES::SPP * ES::stride(NT);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int src_lane = (jj + 4 * r) + 16 * jj;
-    const double q_s = __shfl(quad_sum, src_lane);
-    const double ld_s = __shfl(logd_sum, src_lane);
-    const int64_t slot_s = slot0 + jj + 4 * r;
-    const double ll = factor_round<NTW, TS, TW>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
-                                                   q_s, ld_s, m.n_kept);
-    if (role == 0 && s == 0) {
+  for (int p = 0; p < ES::PASSES; ++p) {
+    int sigma;
+    bool writer;
+    const double ll = factor_pass<double, NTW, TS, TW>(acc, p, Eg, lane, role, tile0, a.k, quad_sum,
+                                                       logd_sum, m.n_kept, &sigma, &writer);
+    const int64_t slot_s = slot0 + sigma;
+    if (writer) {
       if (slot_s < a.S) {
         if (a.mode == 0) a.sample_ll_lls[q * a.S + slot_s] = ll - a.log_S;                 // multi :376-378
         else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ll - a.log_S;  // :359-361

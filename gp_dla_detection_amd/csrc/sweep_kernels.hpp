@@ -497,17 +497,17 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
   return fma(y, err, y);
 }
 
-// The factorisation proper, on one sample's columns already in LDS.  ROWS = ceil((k+1)/16) rows
-// per lane at most.  Returns log N(y; a mu, ...) of that sample (log_mvnpdf_low_rank.m:30-32) in
-// every lane of the row.  q_s = Sum r^2/d, ld_s = Sum log d of the sample.
-template <int ROWS>
+// The factorisation proper, on one sample's columns already in LDS, by LPS lanes (s = 0..LPS-1);
+// ROWS = ceil((k+1)/LPS) rows per lane at most.  Returns log N(y; a mu, ...) of that sample
+// (log_mvnpdf_low_rank.m:30-32) in every lane of the group.  q_s = Sum r^2/d, ld_s = Sum log d.
+template <int ROWS, int LPS>
 __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, double q_s, double ld_s,
                                           int n_kept) {
   int ro[ROWS];
   double dd[ROWS];
 #pragma unroll
   for (int a = 0; a < ROWS; ++a) {
-    const int i = s + 16 * a;
+    const int i = s + LPS * a;
     ro[a] = i < k ? i * (i + 1) / 2 : voff;        // rows beyond k alias v and are never written
     dd[a] = i < k ? e[ro[a] + i] + 1.0 : 0.0;      // log_mvnpdf_low_rank.m:22-23
   }
@@ -517,9 +517,10 @@ __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, 
   for (int j = 0; j < k; ++j) {
     const int rj = j * (j + 1) / 2;
     double dsel = dd[0];
-    if (ROWS > 1 && j >= 16) dsel = dd[1];
-    if (ROWS > 2 && j >= 32) dsel = dd[ROWS > 2 ? 2 : 0];
-    const double dj = __shfl(dsel, j & 15, 16);    // pivot, from the lane that owns row j
+#pragma unroll
+    for (int a = 1; a < ROWS; ++a)
+      if (j >= LPS * a) dsel = dd[a];
+    const double dj = __shfl(dsel, j & (LPS - 1), LPS);  // pivot, from the lane that owns row j
     double t[ROWS];
 #pragma unroll
     for (int a = 0; a < ROWS; ++a) t[a] = e[ro[a] + j];
@@ -536,7 +537,7 @@ __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, 
     lprod = __builtin_amdgcn_frexp_mant(lprod);
 #pragma unroll
     for (int a = 0; a < ROWS; ++a) {
-      const int i = s + 16 * a;
+      const int i = s + LPS * a;
       t[a] *= inv;
       if (i > j && i <= k) {
         e[ro[a] + j] = t[a];
@@ -547,32 +548,68 @@ __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, 
     __builtin_amdgcn_wave_barrier();
   }
   double zsel = dd[0];
-  if (ROWS > 1 && k >= 16) zsel = dd[1];
-  if (ROWS > 2 && k >= 32) zsel = dd[ROWS > 2 ? 2 : 0];
-  const double zz = -__shfl(zsel, k & 15, 16);     // z'z with z = L^-1 v
+#pragma unroll
+  for (int a = 1; a < ROWS; ++a)
+    if (k >= LPS * a) zsel = dd[a];
+  const double zz = -__shfl(zsel, k & (LPS - 1), LPS);  // z'z with z = L^-1 v
   const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
   const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32
   return pd ? ll : NAN;
 }
 
-template <int NTW, int TS, int TW, typename ACC>
-__device__ __forceinline__ double factor_round(const ACC (&acc)[NTW], int r, double *e, int s,
-                                               int role, int tile0, int k, double q_s, double ld_s,
-                                               int n_kept) {
+// Samples factored per pass by one wave (and LDS rows of 16*NT doubles it needs for them): with
+// k <= 20 (TW = 14) 8 lanes per sample and three rows per lane, so 8 samples = two result
+// registers per pass; with k <= 40 (TW = 52) 16 lanes per sample, one result register per pass.
+template <int TW> struct EpilogueShape {
+  static constexpr int LPS = TW > 30 ? 16 : 8;       // lanes per sample
+  static constexpr int RPP = 16 / LPS;               // MFMA result registers per pass
+  static constexpr int PASSES = 4 / RPP;
+  static constexpr int SPP = 4 * RPP;                // samples per pass
+  static constexpr int ROWS = 3;                     // ceil(41/16) = ceil(21/8) = 3
+  // LDS doubles per sample: its 16*NT columns + 4.  Without the pad every sample's copy of a row
+  // starts on the same bank (16*NT*8 bytes is a multiple of the 256-byte bank cycle) and the SPP
+  // samples a wave factors at once conflict SPP-way on every read; +32 bytes staggers them.
+  static constexpr int stride(int nt) { return nt * 16 + 4; }
+};
+
+// One epilogue pass: spill the result registers RPP*p .. of every tile (the 16 lanes of row jj
+// hold, in register r, the 16*NT columns of sample sample_of(jj, r)) to LDS and factor them.
+// Returns the sample's log-likelihood; *sigma_out = its index among the wave's 16, *writer = this
+// lane is the one that stores it.
+template <typename T, int NTW, int TS, int TW, typename ACC>
+__device__ __forceinline__ double factor_pass(const ACC (&acc)[NTW], int p, double *Eg, int lane,
+                                              int role, int tile0, int k, double quad_sum,
+                                              double logd_sum, int n_kept, int *sigma_out,
+                                              bool *writer) {
+  using ES = EpilogueShape<TW>;
   constexpr int voff = TW * 16;
-  constexpr int ROWS = TW > 30 ? 3 : 2;  // TW = 14: k <= 20 (rows 0..20); TW = 52: k <= 40
+  constexpr int ncols = ES::stride(NTW * TS);
+  const int s = lane & 15, jj = lane >> 4;
+  const int half = ES::RPP == 2 ? (s >> 3) : 0;
+  const int sigma = Mat<T>::sample_of(jj, ES::RPP * p + half);
+  // the sample's scalar sums live in the lanes whose s equals sigma
+  const double q_s = __shfl(quad_sum, sigma + 16 * jj);
+  const double ld_s = __shfl(logd_sum, sigma + 16 * jj);
+  double *e = Eg + (size_t)(jj * ES::RPP) * ncols;
   if (TS > 1) __syncthreads();
 #pragma unroll
-  for (int cc = 0; cc < NTW; ++cc) e[(tile0 + cc) * 16 + s] = (double)acc[cc][r];
+  for (int cc = 0; cc < NTW; ++cc)
+#pragma unroll
+    for (int h = 0; h < ES::RPP; ++h)
+      e[h * ncols + (tile0 + cc) * 16 + s] = (double)acc[cc][ES::RPP * p + h];
   if (TS > 1) __syncthreads();
   else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  *sigma_out = sigma;
+  *writer = role == 0 && (s & (ES::LPS - 1)) == 0;
 #ifdef GPDLA_ABLATE_NOEPI
   return q_s + ld_s + e[0];
 #else
-  return role == 0 ? factor_lds<ROWS>(e, s, k, voff, q_s, ld_s, n_kept) : NAN;
+  return role == 0 ? factor_lds<ES::ROWS, ES::LPS>(e + half * ncols, s & (ES::LPS - 1), k, voff, q_s,
+                                                   ld_s, n_kept)
+                   : NAN;
 #endif
 }
 
@@ -936,22 +973,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   logd_sum += __shfl_xor(logd_sum, 32);
 
 #undef GPDLA_RAW_ACCURATE
-  // ---- epilogue: four rounds of factor_round (MFMA result register r = 0..3) ----------------
-  constexpr int ncols = NT * 16;
-  double *Eg = stage + (size_t)group * 4 * ncols;  // [4 samples][ncols] for this sample group
+  // ---- epilogue: factor_pass over the MFMA result registers ------------------------------------
+  using ES = EpilogueShape<TW>;
+  double *Eg = stage + (size_t)group * ES::SPP * ES::stride(NT);  // [SPP samples][stride] of this group
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    // register r of lane group jj holds sample sigma of the wave's 16; its scalars live in the
-    // lanes whose s equals sigma
-    const int sigma = Mat<T>::sample_of(jj, r);
-    const int src_lane = sigma + 16 * jj;
-    const double q_s = __shfl(quad_sum, src_lane);
-    const double ld_s = __shfl(logd_sum, src_lane);
+  for (int p = 0; p < ES::PASSES; ++p) {
+    int sigma;
+    bool writer;
+    const double ll = factor_pass<T, NTW, TS, TW>(acc, p, Eg, lane, role, tile0, a.k, quad_sum, logd_sum,
+                                                  m.n_kept, &sigma, &writer);
     const int64_t slot_s = slot0 + sigma;
-    const int32_t sample_s = __shfl(sample, src_lane);
-    const double ll = factor_round<NTW, TS, TW>(acc, r, Eg + (size_t)jj * ncols, s, role, tile0, a.k,
-                                                   q_s, ld_s, m.n_kept);
-    if (role == 0 && s == 0) {
+    const int32_t sample_s = __shfl(sample, sigma + 16 * jj);
+    if (writer) {
       if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
       else if (slot_s == a.S) a.ll_no_dla[q] = ll;
     }
