@@ -71,11 +71,13 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
       near |= x2 < 900.0;
       total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
     }
-    if (__any(near)) {
+    if (__any(near)) {  // accurate tier: per-line piecewise polynomials (near_tables.hpp), as in k_sweep
       total = 0.0;
       for (int j = 0; j < L; ++j) {
-        const double x = (lamP * s_mult[wave][j] - c_light) * inv_s;
-        total = fma(g_lines.leading[j], rew_full(x, g_lines.y[j]) * 1.7724538509055159, total);
+        const double ax = fabs((lamP * s_mult[wave][j] - c_light) * inv_s);
+        total += ax < 30.0 ? 1.7724538509055159 * g_lines.leading[j] *
+                                 near_poly(g_lines.near_poly + j * kNearLineDoubles, ax)
+                           : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
       }
     }
     const double raw = exp_nonpos(nscale * total);  // voigt.c:291
