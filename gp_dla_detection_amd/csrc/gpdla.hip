@@ -99,7 +99,7 @@ int ensure_line_table(int device_id) {
     t.y[i] = gam[i] / std::sqrt(2.0) / sigma;
     t.y2[i] = t.y[i] * t.y[i];
     t.cwing[i] = lead[i] * t.y[i];
-    t.m2y2[i] = -2.0 * t.y2[i];
+    t.t2[i] = kT2 - 2.0 * t.y2[i];
   }
   for (int i = 0; i < 7; ++i) t.taps[i] = taps[i];
   t.c = GPDLA_SPEED_OF_LIGHT_CGS;
@@ -451,7 +451,7 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   // the epilogue reuses the whole dynamic array (stage buffers, then rings etc.: all dead by then)
   const size_t loop_doubles = stage_doubles + (size_t)WAVES * kSamplesPerWave * kRing2 + kExpTab +
                               (size_t)groups * kSamplesPerWave * L;
-  const size_t lds = std::max(loop_doubles, epi_doubles) * sizeof(double);
+  const size_t lds = std::max(loop_doubles, epi_doubles + kExpTab) * sizeof(double);  // (the epilogue rows start after the exp table)
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "sweep needs %zu B of LDS", lds);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<T, WAVES, NTW, TS, CH, TW, LINES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

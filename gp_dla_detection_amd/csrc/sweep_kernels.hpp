@@ -67,7 +67,7 @@ struct LineTable {
   double y[kMaxLines];              // gamma_j / (sqrt2 sigma): damping parameter of w(z)
   double y2[kMaxLines];             // y_j^2
   double cwing[kMaxLines];          // leading_j * y_j            (wing formula prefactor)
-  double m2y2[kMaxLines];           // -2 y_j^2                   (wing formula correction)
+  double t2[kMaxLines];             // 15/4 - 2 y_j^2: rho^2 coefficient of T(rho) - 2 y^2 rho^2 (wing formula)
   double taps[7];                   // voigt.c:242-251
   double c;                         // voigt.c:22
   double inv_sqrt2_sigma;           // 1/(sqrt2 sigma)
@@ -639,21 +639,22 @@ __device__ __forceinline__ double near_poly(const double *line_tab, double ax) {
 __device__ __forceinline__ double wing_sum3(double lamP, double msa, double msb, double msc, double cs,
                                             bool *near) {
   const double xa = fma(lamP, msa, -cs), xb = fma(lamP, msb, -cs), xc = fma(lamP, msc, -cs);
-  const double x2a = xa * xa, x2b = xb * xb, x2c = xc * xc;
-  *near = (x2a < 900.0) | (x2b < 900.0) | (x2c < 900.0);
-  const double sa = x2a + g_lines.y2[0], sb = x2b + g_lines.y2[1], sc = x2c + g_lines.y2[2];
+  // x^2 + y^2 in one FMA; "near" is then tested on it (a threshold shift of y^2 <= 3e-7 in x^2,
+  // immaterial: both tiers are accurate on either side of |x| = 30)
+  const double sa = fma(xa, xa, g_lines.y2[0]), sb = fma(xb, xb, g_lines.y2[1]), sc = fma(xc, xc, g_lines.y2[2]);
+  *near = (sa < 900.0) | (sb < 900.0) | (sc < 900.0);
   const double pab = sa * sb, pbc = sb * sc, pac = sa * sc;
   const double rinv = fast_rcp(pab * sc);
   const double ra = rinv * pbc, rb = rinv * pac, rc = rinv * pab;
-  double ta = fma(kT6, ra, kT5), tb = fma(kT6, rb, kT5), tc = fma(kT6, rc, kT5);
+  // T(rho) - 2 y^2 rho^2 by Horner; the -2 y_j^2 correction rides in the rho^2 coefficient (t2[j]).
+  // The leading step is a multiply and an add (not an FMA onto a preloaded constant: that costs
+  // two extra moves per line on this ISA); the term it rounds is <= 4e-15 of the sum.
+  double ta = ra * kT6 + kT5, tb = rb * kT6 + kT5, tc = rc * kT6 + kT5;
   ta = fma(ta, ra, kT4); tb = fma(tb, rb, kT4); tc = fma(tc, rc, kT4);
   ta = fma(ta, ra, kT3); tb = fma(tb, rb, kT3); tc = fma(tc, rc, kT3);
-  ta = fma(ta, ra, kT2); tb = fma(tb, rb, kT2); tc = fma(tc, rc, kT2);
+  ta = fma(ta, ra, g_lines.t2[0]); tb = fma(tb, rb, g_lines.t2[1]); tc = fma(tc, rc, g_lines.t2[2]);
   ta = fma(ta, ra, kT1); tb = fma(tb, rb, kT1); tc = fma(tc, rc, kT1);
   ta = fma(ta, ra, kT0); tb = fma(tb, rb, kT0); tc = fma(tc, rc, kT0);
-  ta = fma(g_lines.m2y2[0] * ra, ra, ta);
-  tb = fma(g_lines.m2y2[1] * rb, rb, tb);
-  tc = fma(g_lines.m2y2[2] * rc, rc, tc);
   return fma(g_lines.cwing[2], rc * tc, fma(g_lines.cwing[1], rb * tb, g_lines.cwing[0] * (ra * ta)));
 }
 
@@ -751,10 +752,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   const int s = lane & 15, jj = lane >> 4;
   const int L = LINES > 0 ? LINES : a.num_lines;
 
-  double *stage = smem;                                            // [2][kChunkSteps][RD]
+  double *exp_tab = smem;                                          // [64] at LDS address 0: its index
+                                                                   // needs no base add in the K-loop
+  double *stage = exp_tab + kExpTab;                               // [2][kChunkSteps][RD]
   double *ring = stage + (size_t)2 * kChunkSteps * RD;             // [WAVES][16][33]
-  double *exp_tab = ring + WAVES * kSamplesPerWave * kRing2;       // [64]
-  double *mult_s = exp_tab + kExpTab;                              // [GROUPS*16][L]
+  double *mult_s = ring + WAVES * kSamplesPerWave * kRing2;        // [GROUPS*16][L]
 
   const int64_t slot0 = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave;
   const int64_t slot = slot0 + s;
@@ -933,9 +935,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         const double w = a2 * inv_d;
         const double u = absorb * r * inv_d;
         quad_sum = fma(r * r, inv_d, quad_sum);
-        dprod *= d;  // Sum log d as the log of a running product, renormalised every step
-        dexp += __builtin_amdgcn_frexp_exp(dprod);
-        dprod = __builtin_amdgcn_frexp_mant(dprod);
+        // Sum log d as the log of a running product, renormalised every second step (the
+        // mantissa times two factors stays in range for any d in [1e-150, 1e150])
+        dprod *= d;
+        if (kChunkSteps != 4 || (tt & 1)) {
+          dexp += __builtin_amdgcn_frexp_exp(dprod);
+          dprod = __builtin_amdgcn_frexp_mant(dprod);
+        }
         // next step's wavelength, in flight during the MFMA burst
         if (tt + 1 < kChunkSteps) {
           lam_next = extra[RD + 16 + jj];
