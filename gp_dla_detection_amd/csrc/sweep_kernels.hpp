@@ -678,13 +678,12 @@ __device__ __forceinline__ double exp_table(double x, const double *tab) {
   return ldexp(tab[ni & (kExpTab - 1)] * p, ni >> 6);
 }
 
-// Raw profile value where some line is within 30 Doppler widths (voigt.c:282-291, reference
-// two-rounding velocity): per line either the piecewise polynomial or the wing formula, a few
-// dozen instructions inline -- no call, no divergent trapezoid sums.
+// Optical-depth sum sqrt(pi) Sum_j lead_j Re w_j where some line is within 30 Doppler widths
+// (voigt.c:282-289, reference two-rounding velocity): per line either the piecewise polynomial or
+// the wing formula, a few dozen instructions inline -- no call, no divergent trapezoid sums.
 template <int LINES>
-__device__ __forceinline__ double raw_near(double lamP, double m0, double m1, double m2,
-                                           const double *mult_lds, int L, double nscale,
-                                           const double *exp_tab) {
+__device__ __forceinline__ double total_near(double lamP, double m0, double m1, double m2,
+                                             const double *mult_lds, int L) {
   const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
   const double *tab = g_lines.near_poly;
   double total = 0.0;  // sqrt(pi) Sum_j lead_j Re w_j, the convention of the wing tier
@@ -707,7 +706,7 @@ __device__ __forceinline__ double raw_near(double lamP, double m0, double m1, do
       total += f;
     }
   }
-  return exp_table(nscale * total, exp_tab);
+  return total;
 }
 
 // Diagnostic build only (-DGPDLA_STAMP, tools/stamps.sh): s_memtime brackets around the segments of
@@ -806,9 +805,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
   for (int j = 0; j < (LINES > 0 ? LINES : 0); ++j) ms_r[j] = mult_r[j] * inv_s;
   const double cs = c_light * inv_s;
-#define GPDLA_RAW_ACCURATE(lamP)                                                        \
-  raw_near<LINES>((lamP), mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], \
-                  my_mult, L, nscale, exp_tab)
+#define GPDLA_TOTAL_ACCURATE(lamP)                                                        \
+  total_near<LINES>((lamP), mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], \
+                    my_mult, L)
+#define GPDLA_RAW_ACCURATE(lamP) exp_table(nscale * GPDLA_TOTAL_ACCURATE(lamP), exp_tab)
 
   __syncthreads();  // multipliers and the exp table visible
   // prime the ring with padded pixels 0..11 (the raw profile runs three K-steps ahead)
@@ -901,23 +901,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
             total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
           }
         }
-        double raw = exp_table(nscale * total, exp_tab);
-        GPDLA_ST(0)  // operand requests + wing-tier raw profile
+        GPDLA_ST(0)  // operand requests + wing-tier optical depth
 #ifndef GPDLA_ABLATE_NOSLOW
-        if (__builtin_expect(__any(near), 0)) raw = GPDLA_RAW_ACCURATE(lamP);
+        if (__builtin_expect(__any(near), 0)) total = GPDLA_TOTAL_ACCURATE(lamP);
 #endif
         GPDLA_ST(1)  // accurate tier
-#ifdef GPDLA_ABLATE_NOVOIGT
-        raw = lamP * 1e-4;
-#endif
         // B fragments of this step: requested only now, so that they are not live across the
-        // accurate-tier call above (which would park accumulators in scratch to make room); they
-        // land during the broadening and weight arithmetic.
+        // accurate-tier branch above (it would spill to make room); they land during the rest of
+        // the step, which is ONE basic block from here on: the exp chain of the raw profile and the
+        // broadening / weight chain of this step's pixel are independent, and the scheduler
+        // interleaves them, so a wave running alone on its SIMD does not sit out their latencies.
         const T *bt = reinterpret_cast<const T *>(rec) + (size_t)tile0 * 64 + lane;
         T bop[NTW];
 #pragma unroll
         for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
         __builtin_amdgcn_sched_barrier(0);
+        double raw = exp_table(nscale * total, exp_tab);
+#ifdef GPDLA_ABLATE_NOVOIGT
+        raw = lamP * 1e-4;
+#endif
         my_ring[slot_w] = raw;
         my_ring[slot_w + 16] = raw;
         // (2) instrument broadening for pixel 4 rn + jj: voigt.c:297-299 (symmetric taps)
@@ -971,6 +973,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #endif
   }
 #undef GPDLA_RAW_ACCURATE
+#undef GPDLA_TOTAL_ACCURATE
   // per-sample scalar sums: combine the four pixel phases jj of each sample
   double logd_sum = log(dprod) + (double)dexp * 0.6931471805599453;
   quad_sum += __shfl_xor(quad_sum, 16);
