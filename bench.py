@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2048 flop / 64 cycles x 2.4 GHz
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md (study variant only)
 
 
 def algorithmic_flops(n: int, k: int) -> float:
@@ -179,6 +180,7 @@ def main():
     value = total_evals / elapsed
     flops = algorithmic_flops(args.pixels, args.k) * evals_per_step
     achieved = flops / (sweep_ms * 1e-3) / 1e12
+    peak = FP64_MFMA_PEAK_TFLOPS if args.contraction == "f64" else FP32_MFMA_PEAK_TFLOPS
 
     out = None
     if rank == 0:
@@ -201,8 +203,8 @@ def main():
                        "dla_samples": args.samples, "num_lines": 3,
                        "parallelism": f"spectra sharded over {world} GPU(s), RCCL all-gather of "
                                       "the 12-column posterior table"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(args), "traffic_unit": "bytes/launch (rocprofv3 PMC, "
                          "profiles/pmc_latest.json)", "kernel": "k_sweep", "kernel_ms": sweep_ms,
                          "flops_per_eval": algorithmic_flops(args.pixels, args.k)},
