@@ -447,7 +447,7 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   const int L = args.num_lines;
   const size_t RD = (size_t)record_doubles(b->ntiles, sizeof(T) == 4);
   const size_t stage_doubles = 2 * (size_t)CH * RD;
-  const size_t epi_doubles = (size_t)groups * EpilogueShape<TW>::SPP * EpilogueShape<TW>::stride(b->ntiles);
+  const size_t epi_doubles = (size_t)groups * EpilogueShape<TW, TS>::SPP * EpilogueShape<TW, TS>::stride(b->ntiles);
   // the epilogue reuses the whole dynamic array (stage buffers, then rings etc.: all dead by then)
   const size_t loop_doubles = stage_doubles + (size_t)WAVES * kSamplesPerWave * kRing2 + kExpTab +
                               (size_t)groups * kSamplesPerWave * L;
@@ -565,7 +565,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
     else rc = three ? launch_sweep<float, 8, 16, 1, 4, 14, 3>(c, b, sa) : launch_sweep<float, 8, 16, 1, 4, 14, 0>(c, b, sa);
   } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles
     if (!f32)  // fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
-      rc = three ? launch_sweep<double, 8, 14, 4, 1, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
+      rc = three ? launch_sweep<double, 8, 14, 4, 2, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
     else       // fp32: 224 accumulator registers fit one wave (4-wave blocks, one wave per SIMD)
       rc = three ? launch_sweep<float, 4, 56, 1, 4, 52, 3>(c, b, sa) : launch_sweep<float, 4, 56, 1, 4, 52, 0>(c, b, sa);
   } else {
@@ -740,7 +740,7 @@ int launch_sweep_multi(gpdla_context *c, gpdla_batch *b, SweepMultiArgs args) {
   const size_t RD = (size_t)b->ntiles * 64 + 32;
   // stage buffers during the loop; the epilogue reuses the array for its factorisation rows
   const size_t lds = std::max(2 * (size_t)CH * RD,
-                              (size_t)groups * EpilogueShape<TW>::SPP * EpilogueShape<TW>::stride(b->ntiles)) * sizeof(double);
+                              (size_t)groups * EpilogueShape<TW, TS>::SPP * EpilogueShape<TW, TS>::stride(b->ntiles)) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "multi sweep needs %zu B of LDS", lds);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_multi<NTW, TS, CH, TW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -162,7 +162,6 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   double quad_sum = 0.0, dprod = 1.0;
   int dexp = 0;
   const int tile0 = role * NTW;
-  const int nw = TS == 1 ? TW : max(0, min(NTW, TW - tile0));
 
   // absorption of pixel p for this lane's sample: product of the gathered profiles
   auto absorption = [&](int p) -> double {
@@ -211,7 +210,12 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     const double wa = w_cur, ua = u_cur;
 #pragma unroll
     for (int cc = 0; cc < NTW; ++cc)
-      acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? wa : ua, bop[cc], acc[cc], 0, 0, 0);
+    {
+      constexpr int kTail = TS == 1 ? 0 : NT - TW;
+      const double a_tail = role == TS - 1 ? ua : wa;
+      const double aop = TS == 1 ? (cc < TW ? wa : ua) : (cc < NTW - kTail ? wa : a_tail);
+      acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[cc], acc[cc], 0, 0, 0);
+    }
     GPDLA_MPREP(rec, a_next)
   }
 #undef GPDLA_MPREP
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   logd_sum += __shfl_xor(logd_sum, 16);
   logd_sum += __shfl_xor(logd_sum, 32);
 
-  using ES = EpilogueShape<TW>;
+  using ES = EpilogueShape<TW, TS>;
   double *Eg = stage + (size_t)group * ES::SPP * ES::stride(NT);
 #pragma unroll
   for (int p = 0; p < ES::PASSES; ++p) {

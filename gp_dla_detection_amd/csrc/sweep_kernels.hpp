@@ -557,15 +557,18 @@ __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, 
   return pd ? ll : NAN;
 }
 
-// Samples factored per pass by one wave (and LDS rows of 16*NT doubles it needs for them): with
-// k <= 20 (TW = 14) 8 lanes per sample and three rows per lane, so 8 samples = two result
-// registers per pass; with k <= 40 (TW = 52) 16 lanes per sample, one result register per pass.
-template <int TW> struct EpilogueShape {
-  static constexpr int LPS = TW > 30 ? 16 : 8;       // lanes per sample
+// Samples factored per pass by one wave (and LDS rows of 16*NT doubles it needs for them): 8 lanes
+// per sample, i.e. 8 samples = two MFMA result registers per pass, with three rows per lane for
+// k <= 20 (TW = 14) and six for k <= 40 (TW = 52).  The factorisation is a latency chain of k
+// column steps per pass, so fewer, fatter passes win.
+template <int TW, int TS> struct EpilogueShape {
+  // (k <= 40 without a tile split -- the fp32 study kernel, one wave per sample group -- keeps 16
+  // lanes per sample: 8 samples x 56 tiles per wave would not fit the LDS)
+  static constexpr int LPS = (TW > 30 && TS == 1) ? 16 : 8;  // lanes per sample
   static constexpr int RPP = 16 / LPS;               // MFMA result registers per pass
   static constexpr int PASSES = 4 / RPP;
   static constexpr int SPP = 4 * RPP;                // samples per pass
-  static constexpr int ROWS = 3;                     // ceil(41/16) = ceil(21/8) = 3
+  static constexpr int ROWS = TW > 30 ? 48 / LPS : 3;  // ceil(41/LPS); ceil(21/8)
   // LDS doubles per sample: its 16*NT columns + 4.  Without the pad every sample's copy of a row
   // starts on the same bank (16*NT*8 bytes is a multiple of the 256-byte bank cycle) and the SPP
   // samples a wave factors at once conflict SPP-way on every read; +32 bytes staggers them.
@@ -581,7 +584,7 @@ __device__ __forceinline__ double factor_pass(const ACC (&acc)[NTW], int p, doub
                                               int role, int tile0, int k, double quad_sum,
                                               double logd_sum, int n_kept, int *sigma_out,
                                               bool *writer) {
-  using ES = EpilogueShape<TW>;
+  using ES = EpilogueShape<TW, TS>;
   constexpr int voff = TW * 16;
   constexpr int ncols = ES::stride(NTW * TS);
   const int s = lane & 15, jj = lane >> 4;
@@ -728,13 +731,16 @@ __device__ unsigned long long g_stamps[8];
 #endif
 
 // Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk
-// (must be 4: the step loop is unrolled over the chunk so ring slots are compile-time),
+// (4, or 2 with two chunks unrolled: ring slots are then compile-time; 1: run-time slots),
 // TW tiles that take the weight w (the rest take u; TS*NTW tiles in all, zero-padded), LINES
 // number of Lyman lines when known at compile time (0: read num_lines at run time).
 template <typename T, int WAVES, int NTW, int TS, int kChunkSteps, int TW, int LINES>
 __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   extern __shared__ double smem[];
-  static_assert(kChunkSteps == 4 || kChunkSteps == 1, "step loop is written for chunks of 4 (or 1)");
+  static_assert(kChunkSteps == 4 || kChunkSteps == 2 || kChunkSteps == 1, "chunks of 4, 2 or 1 K-steps");
+  // chunks unrolled per loop iteration so that 4 K-steps (one turn of the 16-slot ring) are
+  // straight-line code with compile-time ring slots and stage-buffer addresses
+  constexpr int UN = kChunkSteps == 2 ? 2 : 1;
   constexpr int GROUPS = WAVES / TS;  // sample groups per block
   constexpr int NT = NTW * TS;
   constexpr int TD = 64 * (int)sizeof(T) / 8;  // doubles occupied by one 64-element tile
@@ -856,7 +862,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
     st_prev = (uint32_t)t0_;
   }
 #endif
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c0 = 0; c0 < nchunks; c0 += UN) {
+#pragma unroll
+  for (int hc = 0; hc < UN; ++hc) {
+    const int c = c0 + hc;
+    if (UN > 1 && c >= nchunks) break;  // block-uniform
     // Nothing of ours is in flight here (drained before the barrier), so this wait is free; it is
     // for the compiler, whose scratch reloads of the loop preheader would otherwise be waited for
     // inside the K-steps -- behind the prefetch issued on the next line.
@@ -864,7 +874,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
     GPDLA_ST(4)  // chunk-end drain + barrier
     if (c + 1 < nchunks) issue_chunk(c + 1);  // lands in the other buffer while we compute
     GPDLA_ST(5)  // prefetch issue
-    const double *buf = stage + (size_t)(c & 1) * kChunkSteps * RD;
+    const double *buf = stage + (size_t)(UN > 1 ? hc : (c & 1)) * kChunkSteps * RD;  // UN = 2: c0 is even
     double lam_next = 0.0;
 #pragma unroll
     for (int tt = 0; tt < kChunkSteps; ++tt) {
@@ -873,7 +883,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         const double *rec = buf + (size_t)tt * RD;
         const double *extra = rec + NT * TD;
         // ring slot of pixel 4 rn (+ jj, folded into my_ring); compile-time when chunks are 4 long
-        const int slot_p = kChunkSteps == 4 ? 4 * tt : ((4 * rn) & 15);
+        const int slot_p = kChunkSteps == 4 ? 4 * tt : (kChunkSteps == 2 ? 4 * (2 * hc + tt) : ((4 * rn) & 15));
         const int slot_w = (slot_p + 12) & 15;
         // lam_next was requested before the previous MFMA burst and has long landed: saying so
         // (s_waitcnt lgkmcnt(0), free) lets the raw chain start under the 15 reads issued next
@@ -940,7 +950,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         // Sum log d as the log of a running product, renormalised every second step (the
         // mantissa times two factors stays in range for any d in [1e-150, 1e150])
         dprod *= d;
-        if (kChunkSteps != 4 || (tt & 1)) {
+        if (kChunkSteps == 1 || (tt & 1)) {
           dexp += __builtin_amdgcn_frexp_exp(dprod);
           dprod = __builtin_amdgcn_frexp_mant(dprod);
         }
@@ -958,9 +968,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
           if (cc < 2) acc[cc][0] += (T)(cc < nw ? w : u) * bop[cc];
         }
 #else
+        // With a tile split only the last role's last NT - TW tiles take u; one wave-uniform
+        // select per step instead of one per tile.
+        constexpr int kTail = TS == 1 ? 0 : NT - TW;
+        static_assert(TS == 1 || kTail <= NTW, "u-tiles must sit in the last role's tiles");
+        const T a_tail = (T)(role == TS - 1 ? u : w);
 #pragma unroll
-        for (int cc = 0; cc < NTW; ++cc)
-          acc[cc] = Mat<T>::mfma((T)(cc < nw ? w : u), bop[cc], acc[cc]);
+        for (int cc = 0; cc < NTW; ++cc) {
+          const T aop = TS == 1 ? (T)(cc < TW ? w : u) : (cc < NTW - kTail ? (T)w : a_tail);
+          acc[cc] = Mat<T>::mfma(aop, bop[cc], acc[cc]);
+        }
 #endif
         GPDLA_ST(3)  // MFMA burst (issue)
       }
@@ -971,6 +988,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
     glds_wait();  // the prefetched chunk has landed (this wave's part) ...
     __syncthreads();  // ... and everyone's; all reads of the buffer refilled next are done
 #endif
+  }
   }
 #undef GPDLA_RAW_ACCURATE
 #undef GPDLA_TOTAL_ACCURATE
@@ -983,7 +1001,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 
 #undef GPDLA_RAW_ACCURATE
   // ---- epilogue: factor_pass over the MFMA result registers ------------------------------------
-  using ES = EpilogueShape<TW>;
+  using ES = EpilogueShape<TW, TS>;
   double *Eg = stage + (size_t)group * ES::SPP * ES::stride(NT);  // [SPP samples][stride] of this group
 #pragma unroll
   for (int p = 0; p < ES::PASSES; ++p) {
