@@ -557,6 +557,75 @@ __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, 
   return pd ? ll : NAN;
 }
 
+// The same factorisation with each lane's own rows held in registers (k <= KMAX known at compile
+// time, column loop fully unrolled).  The LDS version reads, for every column, the lane's three
+// rows AND the pivot row -- 4 streams, 300 KB per wave and pass, which made the epilogue LDS
+// bandwidth-bound; here only the pivot row (a broadcast within the sample's lanes) comes from LDS,
+// at compile-time offsets.  Same operation order, so results are bit-identical to factor_lds.
+template <int ROWS, int LPS, int KMAX>
+__device__ __forceinline__ double factor_rows(double *e, int s, int k, int voff, double q_s, double ld_s,
+                                           int n_kept) {
+  int ro[ROWS];
+  double dd[ROWS];
+  double rc[ROWS][KMAX];  // rc[a][m] = entry (row s + LPS a, column m): A before column m, L after
+#pragma unroll
+  for (int a = 0; a < ROWS; ++a) {
+    const int i = s + LPS * a;
+    ro[a] = i < k ? i * (i + 1) / 2 : voff;        // rows beyond k alias v and are never written
+    dd[a] = i < k ? e[ro[a] + i] + 1.0 : 0.0;      // log_mvnpdf_low_rank.m:22-23
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) rc[a][m] = e[ro[a] + m];  // (columns >= the row index: unused)
+  }
+  double lprod = 1.0;
+  int lexp = 0;
+  bool pd = true;
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    if (j < k) {  // block-uniform
+      const int rj = j * (j + 1) / 2;
+      double dsel = dd[0];
+#pragma unroll
+      for (int a = 1; a < ROWS; ++a)
+        if (j >= LPS * a) dsel = dd[a];
+      const double dj = __shfl(dsel, j & (LPS - 1), LPS);  // pivot, from the lane that owns row j
+      double t[ROWS];
+#pragma unroll
+      for (int a = 0; a < ROWS; ++a) t[a] = rc[a][j];
+#pragma unroll
+      for (int mm = 0; mm < j; ++mm) {
+        const double c = e[rj + mm];
+#pragma unroll
+        for (int a = 0; a < ROWS; ++a) t[a] = fma(-rc[a][mm], c, t[a]);
+      }
+      pd = pd && (dj > 0.0);                         // chol would throw here (:24)
+      const double inv = rsqrt_nr(dj);
+      lprod *= dj;                                   // 2 Sum log L_jj = log Prod d_j (:30)
+      lexp += __builtin_amdgcn_frexp_exp(lprod);
+      lprod = __builtin_amdgcn_frexp_mant(lprod);
+#pragma unroll
+      for (int a = 0; a < ROWS; ++a) {
+        const int i = s + LPS * a;
+        t[a] *= inv;
+        rc[a][j] = t[a];
+        if (i > j && i <= k) {
+          e[ro[a] + j] = t[a];                       // row i becomes a pivot row later
+          dd[a] = fma(-t[a], t[a], dd[a]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  double zsel = dd[0];
+#pragma unroll
+  for (int a = 1; a < ROWS; ++a)
+    if (k >= LPS * a) zsel = dd[a];
+  const double zz = -__shfl(zsel, k & (LPS - 1), LPS);  // z'z with z = L^-1 v
+  const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
+  const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32
+  return pd ? ll : NAN;
+}
+
 // Samples factored per pass by one wave (and LDS rows of 16*NT doubles it needs for them): 8 lanes
 // per sample, i.e. 8 samples = two MFMA result registers per pass, with three rows per lane for
 // k <= 20 (TW = 14) and six for k <= 40 (TW = 52).  The factorisation is a latency chain of k
@@ -610,9 +679,10 @@ __device__ __forceinline__ double factor_pass(const ACC (&acc)[NTW], int p, doub
 #ifdef GPDLA_ABLATE_NOEPI
   return q_s + ld_s + e[0];
 #else
-  return role == 0 ? factor_lds<ES::ROWS, ES::LPS>(e + half * ncols, s & (ES::LPS - 1), k, voff, q_s,
-                                                   ld_s, n_kept)
-                   : NAN;
+  if (role != 0) return NAN;
+  if (TW <= 14)  // k <= 20: own rows in registers
+    return factor_rows<ES::ROWS, ES::LPS, 20>(e + half * ncols, s & (ES::LPS - 1), k, voff, q_s, ld_s, n_kept);
+  return factor_lds<ES::ROWS, ES::LPS>(e + half * ncols, s & (ES::LPS - 1), k, voff, q_s, ld_s, n_kept);
 #endif
 }
 
