@@ -99,7 +99,7 @@ int ensure_line_table(int device_id) {
     t.y[i] = gam[i] / std::sqrt(2.0) / sigma;
     t.y2[i] = t.y[i] * t.y[i];
     t.cwing[i] = lead[i] * t.y[i];
-    t.t2[i] = kT2 - 2.0 * t.y2[i];
+    t.t2[i] = kE2 - 2.0 * t.y2[i];
   }
   for (int i = 0; i < 7; ++i) t.taps[i] = taps[i];
   t.c = GPDLA_SPEED_OF_LIGHT_CGS;
