@@ -740,21 +740,35 @@ constexpr int kExpTab = 64;  // entries of the 2^(j/64) table behind exp_table()
 
 // exp(x) for x <= 0 through a 64-entry table: x = (64 n + j) ln2/64 + r, |r| <= ln2/128,
 // exp(x) = 2^n * 2^(j/64) * P5(r).  Relative error < 2e-16 (r^6/720 < 3.6e-17).
-__device__ __forceinline__ double exp_table(double x, const double *tab) {
+// In two halves so that a caller can request the table entry early (exp_table_begin), put other
+// LDS traffic behind it, and finish later (exp_table_end) without waiting for that traffic.
+struct ExpState {
+  double r, tabv;
+  int ni;
+};
+__device__ __forceinline__ ExpState exp_table_begin(double x, const double *tab) {
   // no clamp: for x << -745 the integer conversion saturates, ni >> 6 is hugely negative and
   // ldexp returns 0; the reduced argument stays tiny (nf is exact to 0.5 up to |x| ~ 1e13)
+  ExpState e;
   const double nf = rint(x * 92.33248261689366);            // 64 / ln2
-  double r = fma(-nf, 0.010830424667801708, x);               // ln2/64 high part (low 24 bits zero)
-  r = fma(-nf, 2.8447437476627285e-11, r);                    // ln2/64 low part
-  int ni;  // saturating conversion, spelled as the instruction: (int)nf is undefined out of range
-  asm("v_cvt_i32_f64 %0, %1" : "=v"(ni) : "v"(nf));
+  // saturating conversion, spelled as the instruction: (int)nf is undefined out of range
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(e.ni) : "v"(nf));
+  e.tabv = tab[e.ni & (kExpTab - 1)];
+  e.r = fma(-nf, 0.010830424667801708, x);                    // ln2/64 high part (low 24 bits zero)
+  e.r = fma(-nf, 2.8447437476627285e-11, e.r);                // ln2/64 low part
+  return e;
+}
+__device__ __forceinline__ double exp_table_end(const ExpState &e) {
   double p = 0.008333333333333333;
-  p = fma(p, r, 0.041666666666666664);
-  p = fma(p, r, 0.16666666666666666);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(tab[ni & (kExpTab - 1)] * p, ni >> 6);
+  p = fma(p, e.r, 0.041666666666666664);
+  p = fma(p, e.r, 0.16666666666666666);
+  p = fma(p, e.r, 0.5);
+  p = fma(p, e.r, 1.0);
+  p = fma(p, e.r, 1.0);
+  return ldexp(e.tabv * p, e.ni >> 6);
+}
+__device__ __forceinline__ double exp_table(double x, const double *tab) {
+  return exp_table_end(exp_table_begin(x, tab));
 }
 
 // Optical-depth sum sqrt(pi) Sum_j lead_j Re w_j where some line is within 30 Doppler widths
@@ -997,12 +1011,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         // the step, which is ONE basic block from here on: the exp chain of the raw profile and the
         // broadening / weight chain of this step's pixel are independent, and the scheduler
         // interleaves them, so a wave running alone on its SIMD does not sit out their latencies.
+        // (the exp table entry is requested ahead of them: LDS returns in order, and the exp chain
+        // then waits for one read instead of nine)
+        const ExpState es = exp_table_begin(nscale * total, exp_tab);
+        __builtin_amdgcn_sched_barrier(0);
         const T *bt = reinterpret_cast<const T *>(rec) + (size_t)tile0 * 64 + lane;
         T bop[NTW];
 #pragma unroll
         for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
         __builtin_amdgcn_sched_barrier(0);
-        double raw = exp_table(nscale * total, exp_tab);
+        double raw = exp_table_end(es);
 #ifdef GPDLA_ABLATE_NOVOIGT
         raw = lamP * 1e-4;
 #endif
