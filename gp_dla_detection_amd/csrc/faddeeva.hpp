@@ -11,9 +11,11 @@
 //                               folded analytically into the n = 0 node (no cancellation);
 //                               h = 0.4 -> quadrature error exp(-pi^2/h^2) = 1.6e-27.
 //
-// The sweep kernel evaluates rew_wing branch-free for every (pixel, line) and falls back to
-// rew_full under a wave-uniform vote only when some lane is within 30 Doppler widths of a line
-// centre (about 11 pixels per line; samples are processed in z order so those lanes coincide).
+// These tiers serve gpdla_voigt (k_voigt_raw) directly and, evaluated in long double on the host,
+// are what near_tables.hpp fits its per-line polynomials to.  The sweep kernels evaluate the wing
+// formula (economised, sweep_kernels.hpp) branch-free for every (pixel, line) and, under a
+// wave-uniform vote when some lane is within 30 Doppler widths of a line centre (about 11 pixels
+// per line; samples are processed in z order so those lanes coincide), those polynomials.
 #pragma once
 #include <hip/hip_runtime.h>
 

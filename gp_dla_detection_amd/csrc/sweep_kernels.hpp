@@ -383,14 +383,14 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
 // K-step t, on pixel 4t + jj.  Slot S (one past the last sample) is the null model (a = 1):
 // process_qsos.m:149-151.  Samples are visited in ascending z_DLA order (perm), so the lanes of a
 // wave sit within a few pixels of each other relative to every line centre and the accurate
-// Faddeeva branch is taken by whole waves, one line at a time.
+// tier of the Voigt function is taken by whole waves, one line at a time.
 //
 // TS ("tile split"): number of waves that share one group of 16 samples and split the B tiles
 // between them (1 for k <= 20; 4 for k <= 40, where 55 tiles of accumulators do not fit one wave).
 //
-// LDS (one dynamic array): two chunk buffers of kChunkSteps records (global_load_lds double
-// buffering) | raw-profile rings | per-sample line multipliers.  After the loop the chunk buffers
-// are reused by the Cholesky epilogue.
+// LDS (one dynamic array): exp table | two chunk buffers of kChunkSteps records (global_load_lds
+// double buffering) | raw-profile rings | per-sample line multipliers.  After the loop everything
+// behind the exp table is reused by the Cholesky epilogue.
 // ------------------------------------------------------------------------------------------
 constexpr int kSweepWaves = 8;  // waves per block of the fp64 sweeps
 
