@@ -734,22 +734,33 @@ int gpdla_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M
 
 namespace {
 
-template <int NTW, int TS, int CH, int TW>
-int launch_sweep_multi(gpdla_context *c, gpdla_batch *b, SweepMultiArgs args) {
+template <int NTW, int TS, int CH, int TW, int ND>
+int launch_sweep_multi_nd(gpdla_context *c, gpdla_batch *b, SweepMultiArgs args) {
   constexpr int groups = kSweepWaves / TS;
   const size_t RD = (size_t)b->ntiles * 64 + 32;
   // stage buffers during the loop; the epilogue reuses the array for its factorisation rows
   const size_t lds = std::max(2 * (size_t)CH * RD,
                               (size_t)groups * EpilogueShape<TW, TS>::SPP * EpilogueShape<TW, TS>::stride(b->ntiles)) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "multi sweep needs %zu B of LDS", lds);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_multi<NTW, TS, CH, TW>),
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_multi<NTW, TS, CH, TW, ND>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   args.blocks_per_quasar = (int32_t)((args.S + 1 + groups * kSamplesPerWave - 1) / (groups * kSamplesPerWave));
   const int64_t nblocks = 8 * (((int64_t)args.nq_sub + 7) / 8) * (int64_t)args.blocks_per_quasar;
   if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "sub-batch too large for one launch");
-  hipLaunchKernelGGL((k_sweep_multi<NTW, TS, CH, TW>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  hipLaunchKernelGGL((k_sweep_multi<NTW, TS, CH, TW, ND>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
   HIP_TRY(hipGetLastError());
   return GPDLA_OK;
+}
+
+template <int NTW, int TS, int CH, int TW>
+int launch_sweep_multi(gpdla_context *c, gpdla_batch *b, const SweepMultiArgs &args) {
+  switch (args.mode == 0 ? 1 : args.mode) {  // profiles multiplied per sample
+    case 1: return launch_sweep_multi_nd<NTW, TS, CH, TW, 1>(c, b, args);
+    case 2: return launch_sweep_multi_nd<NTW, TS, CH, TW, 2>(c, b, args);
+    case 3: return launch_sweep_multi_nd<NTW, TS, CH, TW, 3>(c, b, args);
+    case 4: return launch_sweep_multi_nd<NTW, TS, CH, TW, 4>(c, b, args);
+    default: return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d > 4", args.mode);
+  }
 }
 
 struct MultiBuffers {

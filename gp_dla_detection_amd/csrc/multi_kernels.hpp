@@ -109,7 +109,10 @@ struct SweepMultiArgs {
   double *ll_no_dla;           // [nq]
 };
 
-template <int NTW, int TS, int kChunkSteps, int TW>
+// ND: number of profiles a sample multiplies (1 for the LLS model and the one-DLA model), known at
+// compile time so that the ND gathers of a K-step are issued back to back ahead of the MFMA burst
+// (with a run-time count each gather sat behind a branch and was waited for before the next).
+template <int NTW, int TS, int kChunkSteps, int TW, int ND>
 __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   extern __shared__ double smem[];
   constexpr int GROUPS = kSweepWaves / TS;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   const bool is_sample = slot < a.S;
   const bool is_null = !is_sample;
   const int64_t i = is_sample ? slot : 0;
-  const int nd = a.mode == 0 ? 1 : a.mode;
+  constexpr int nd = ND;  // a.mode == 0 ? 1 : a.mode
   // rows of the profile table this lane multiplies (multi :342-351)
   const double *rows[4];
   rows[0] = a.prof + ((ql * 2 + (a.mode == 0 ? 1 : 0)) * a.S + i) * a.stride;
@@ -166,9 +169,9 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   // absorption of pixel p for this lane's sample: product of the gathered profiles
   auto absorption = [&](int p) -> double {
     double v = rows[0][p];
-    if (nd > 1) v *= rows[1][p];
-    if (nd > 2) v *= rows[2][p];
-    if (nd > 3) v *= rows[3][p];
+    if (ND > 1) v *= rows[1][p];
+    if (ND > 2) v *= rows[2][p];
+    if (ND > 3) v *= rows[3][p];
     return is_null ? 1.0 : v;
   };
   double a_next = absorption(jj);  // step 0
