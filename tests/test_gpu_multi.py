@@ -94,6 +94,19 @@ def test_gpu_resampling_then_oracle(oracle):
         assert abs(out["p_dlas"][i] - (1 - mp[0] - mp[1])) < 1e-9
 
 
+def test_rank_40_multi_dla(oracle):
+    """The multi-DLA sweep on the k <= 40 kernel (tile split over four waves), every model order."""
+    p = MultiParameters(max_dlas=3)
+    model = synthetic.make_model(40)
+    S = 96
+    samples = synthetic.make_samples(S)
+    spectra = [synthetic.make_spectrum(80 + i, n, model, mask_fraction=0.04) for i, n in enumerate([260, 301])]
+    lp = priors(spectra, p)
+    out = gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=p)
+    for i, sp in enumerate(spectra):
+        compare(out, i, oracle_multi(oracle, model, samples, sp, out["base_sample_inds"][i], p), p)
+
+
 def test_resampling_is_deterministic_and_shard_invariant():
     p = MultiParameters(max_dlas=3)
     model = synthetic.make_model(20)

@@ -186,6 +186,19 @@ def test_rank_40_model(oracle):
     assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL
 
 
+@pytest.mark.parametrize("k", [21, 27, 33])
+def test_ranks_between_the_tile_classes(oracle, k):
+    """20 < k < 40 runs on the k <= 40 kernel with zero-padded tiles: 21 is the first rank past the
+    one-wave class, 27 and 33 leave different numbers of the 52 + 4 tiles (partly) empty."""
+    model = synthetic.make_model(k)
+    samples = synthetic.make_samples(40)
+    sp = synthetic.make_spectrum(52 + k, 333, model, mask_fraction=0.03)
+    out = run_gpu(model, samples, [sp])
+    ref = run_oracle(oracle, model, samples, sp)
+    assert abs(out["log_likelihoods_no_dla"][0] - ref["log_likelihood_no_dla"]) < TOL
+    assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL
+
+
 def test_small_rank_model(oracle):
     model = synthetic.make_model(5)
     samples = synthetic.make_samples(20)
