@@ -38,6 +38,9 @@ struct ProfilesArgs {
 
 __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
   __shared__ double s_mult[4][kMaxLines];
+  __shared__ double s_exp[kExpTab];  // 2^(j/64), the table behind exp_table()
+  if (threadIdx.x < kExpTab) s_exp[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / kExpTab));
+  __syncthreads();  // (before any wave may leave)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t w_global = (int64_t)blockIdx.x * 4 + wave;
   const int64_t per_q = 2 * a.S;
@@ -65,11 +68,16 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
     const double lamP = lam[min(P, n_pad - 1)];
     double total = 0.0;
     bool near = false;
-    for (int j = 0; j < L; ++j) {
-      const double x = (lamP * s_mult[wave][j] - c_light) * inv_s;  // voigt.c:287
-      const double x2 = x * x;
-      near |= x2 < 900.0;
-      total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
+    if (L == 3) {  // the driver's case: the sweep kernel's merged three-line wing tier
+      total = wing_sum3(lamP, s_mult[wave][0] * inv_s, s_mult[wave][1] * inv_s, s_mult[wave][2] * inv_s,
+                        c_light * inv_s, &near);
+    } else {
+      for (int j = 0; j < L; ++j) {
+        const double x = (lamP * s_mult[wave][j] - c_light) * inv_s;  // voigt.c:287
+        const double x2 = x * x;
+        near |= x2 < 900.0;
+        total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
+      }
     }
     if (__any(near)) {  // accurate tier: per-line piecewise polynomials (near_tables.hpp), as in k_sweep
       total = 0.0;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
                            : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
       }
     }
-    const double raw = exp_nonpos(nscale * total);  // voigt.c:291
+    const double raw = exp_table(nscale * total, s_exp);  // voigt.c:291
     double acc = raw * g_lines.taps[0];             // voigt.c:297-299
 #pragma unroll
     for (int kk = 1; kk < 7; ++kk) acc = fma(__shfl_down(raw, kk), g_lines.taps[kk], acc);
