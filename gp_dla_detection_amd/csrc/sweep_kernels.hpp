@@ -508,6 +508,11 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 template <int ROWS, int LPS>
 __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, double q_s, double ld_s,
                                           int n_kept) {
+  // Columns are taken in panels of PW: the part of their dot products that involves earlier
+  // panels (the bulk) is formed for the whole panel at once, so each own-row entry read from LDS
+  // feeds PW multiply-adds instead of one; only the few in-panel terms follow the column-by-column
+  // dependency chain.  The summation order per entry is unchanged (columns ascending).
+  constexpr int PW = 4;
   int ro[ROWS];
   double dd[ROWS];
 #pragma unroll
@@ -519,38 +524,61 @@ __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, 
   double lprod = 1.0;
   int lexp = 0;
   bool pd = true;
-  for (int j = 0; j < k; ++j) {
-    const int rj = j * (j + 1) / 2;
-    double dsel = dd[0];
+  for (int j0 = 0; j0 < k; j0 += PW) {
+    double t[ROWS][PW];
+    int rp[PW];  // pivot rows of the panel (clamped in the last, partial panel: those columns are unused)
 #pragma unroll
-    for (int a = 1; a < ROWS; ++a)
-      if (j >= LPS * a) dsel = dd[a];
-    const double dj = __shfl(dsel, j & (LPS - 1), LPS);  // pivot, from the lane that owns row j
-    double t[ROWS];
+    for (int c = 0; c < PW; ++c) {
+      const int j = min(j0 + c, k - 1);
+      rp[c] = j * (j + 1) / 2;
 #pragma unroll
-    for (int a = 0; a < ROWS; ++a) t[a] = e[ro[a] + j];
-#pragma unroll 4
-    for (int mm = 0; mm < j; ++mm) {
-      const double c = e[rj + mm];
-#pragma unroll
-      for (int a = 0; a < ROWS; ++a) t[a] = fma(-e[ro[a] + mm], c, t[a]);
+      for (int a = 0; a < ROWS; ++a) t[a][c] = e[ro[a] + j0 + c];
     }
-    pd = pd && (dj > 0.0);                         // chol would throw here (:24)
-    const double inv = rsqrt_nr(dj);
-    lprod *= dj;                                   // 2 Sum log L_jj = log Prod d_j (:30)
-    lexp += __builtin_amdgcn_frexp_exp(lprod);
-    lprod = __builtin_amdgcn_frexp_mant(lprod);
+#pragma unroll 2
+    for (int mm = 0; mm < j0; ++mm) {
+      double own[ROWS], piv[PW];
 #pragma unroll
-    for (int a = 0; a < ROWS; ++a) {
-      const int i = s + LPS * a;
-      t[a] *= inv;
-      if (i > j && i <= k) {
-        e[ro[a] + j] = t[a];
-        dd[a] = fma(-t[a], t[a], dd[a]);
+      for (int a = 0; a < ROWS; ++a) own[a] = e[ro[a] + mm];
+#pragma unroll
+      for (int c = 0; c < PW; ++c) piv[c] = e[rp[c] + mm];
+#pragma unroll
+      for (int a = 0; a < ROWS; ++a)
+#pragma unroll
+        for (int c = 0; c < PW; ++c) t[a][c] = fma(-own[a], piv[c], t[a][c]);
+    }
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {
+      const int j = j0 + c;
+      if (j < k) {  // block-uniform
+#pragma unroll
+        for (int cp = 0; cp < c; ++cp) {  // in-panel terms: own entries are still in registers
+          const double pv = e[rp[c] + j0 + cp];
+#pragma unroll
+          for (int a = 0; a < ROWS; ++a) t[a][c] = fma(-t[a][cp], pv, t[a][c]);
+        }
+        double dsel = dd[0];
+#pragma unroll
+        for (int a = 1; a < ROWS; ++a)
+          if (j >= LPS * a) dsel = dd[a];
+        const double dj = __shfl(dsel, j & (LPS - 1), LPS);  // pivot, from the lane that owns row j
+        pd = pd && (dj > 0.0);                         // chol would throw here (:24)
+        const double inv = rsqrt_nr(dj);
+        lprod *= dj;                                   // 2 Sum log L_jj = log Prod d_j (:30)
+        lexp += __builtin_amdgcn_frexp_exp(lprod);
+        lprod = __builtin_amdgcn_frexp_mant(lprod);
+#pragma unroll
+        for (int a = 0; a < ROWS; ++a) {
+          const int i = s + LPS * a;
+          t[a][c] *= inv;
+          if (i > j && i <= k) {
+            e[ro[a] + j] = t[a][c];
+            dd[a] = fma(-t[a][c], t[a][c], dd[a]);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
   double zsel = dd[0];
 #pragma unroll
