@@ -512,7 +512,7 @@ __device__ __forceinline__ double factor_lds(double *e, int s, int k, int voff, 
   // panels (the bulk) is formed for the whole panel at once, so each own-row entry read from LDS
   // feeds PW multiply-adds instead of one; only the few in-panel terms follow the column-by-column
   // dependency chain.  The summation order per entry is unchanged (columns ascending).
-  constexpr int PW = 4;
+  constexpr int PW = ROWS <= 3 ? 8 : 4;
   int ro[ROWS];
   double dd[ROWS];
 #pragma unroll
