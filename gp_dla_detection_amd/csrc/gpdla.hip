@@ -386,9 +386,9 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   b->nq = nq;
   b->S = c->S;
   b->k = c->model.k;
-  // tile classes of the sweep kernel: k <= 20 -> 14 + 2 tiles, k <= 40 -> 52 + 4 tiles
-  b->tiles_w = b->k <= 20 ? 14 : 52;
-  b->ntiles = b->k <= 20 ? 16 : 56;
+  // k <= 20: 13 w-tiles + 1 u-tile (+ 2 + 4 columns on the VALU); k <= 40: 52 + 4 tiles
+  b->tiles_w = b->k <= 20 ? 13 : 52;
+  b->ntiles = b->k <= 20 ? kCompactTiles : 56;
   const int64_t base = sp->offsets[0];
   b->total_pix = sp->offsets[nq] - base;
   std::vector<int64_t> off(nq + 1);
@@ -420,7 +420,7 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   chk(dev_alloc(&b->d_pix, (size_t)rows));
   chk(dev_alloc(&b->d_Mi, (size_t)rows * b->k));
   chk(dev_alloc(&b->d_lam, (size_t)lam));
-  chk(dev_alloc(&b->d_records, (size_t)(rows / 4) * (b->ntiles * 64 + 32)));
+  chk(dev_alloc(&b->d_records, (size_t)(rows / 4) * record_doubles(b->ntiles, 0)));
   chk(dev_alloc(&b->d_sample_ll, (size_t)nq * b->S));
   chk(dev_alloc(&b->d_ll_no, (size_t)nq));
   chk(dev_alloc(&b->d_summary, (size_t)nq * GPDLA_SUMMARY_COLS));
@@ -447,7 +447,7 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   const int L = args.num_lines;
   const size_t RD = (size_t)record_doubles(b->ntiles, sizeof(T) == 4);
   const size_t stage_doubles = 2 * (size_t)CH * RD;
-  const size_t epi_doubles = (size_t)groups * EpilogueShape<TW, TS>::SPP * EpilogueShape<TW, TS>::stride(b->ntiles);
+  const size_t epi_doubles = (size_t)groups * EpilogueShape<TW, TS>::SPP * EpilogueShape<TW, TS>::stride(logical_tiles(b->ntiles));
   // the epilogue reuses the whole dynamic array (stage buffers, then rings etc.: all dead by then)
   const size_t loop_doubles = stage_doubles + (size_t)WAVES * kSamplesPerWave * kRing2 + kExpTab +
                               (size_t)groups * kSamplesPerWave * L;
@@ -560,9 +560,9 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.blocks_per_quasar = 0;  // set by launch_sweep
   const bool three = num_lines == 3;
   const bool f32 = c->cfg.contraction_precision == 1;
-  if (b->k <= 20) {  // 14 w-tiles (<= 210 vech columns) + 2 u-tiles, zero-padded
-    if (!f32) rc = three ? launch_sweep<double, 8, 16, 1, 4, 14, 3>(c, b, sa) : launch_sweep<double, 8, 16, 1, 4, 14, 0>(c, b, sa);
-    else rc = three ? launch_sweep<float, 8, 16, 1, 4, 14, 3>(c, b, sa) : launch_sweep<float, 8, 16, 1, 4, 14, 0>(c, b, sa);
+  if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
+    if (!f32) rc = three ? launch_sweep<double, 8, 14, 1, 4, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
+    else rc = three ? launch_sweep<float, 8, 14, 1, 4, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
   } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles
     if (!f32)  // fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
       rc = three ? launch_sweep<double, 8, 14, 4, 2, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
@@ -737,10 +737,10 @@ namespace {
 template <int NTW, int TS, int CH, int TW, int ND>
 int launch_sweep_multi_nd(gpdla_context *c, gpdla_batch *b, SweepMultiArgs args) {
   constexpr int groups = kSweepWaves / TS;
-  const size_t RD = (size_t)b->ntiles * 64 + 32;
+  const size_t RD = (size_t)record_doubles(b->ntiles, 0);
   // stage buffers during the loop; the epilogue reuses the array for its factorisation rows
   const size_t lds = std::max(2 * (size_t)CH * RD,
-                              (size_t)groups * EpilogueShape<TW, TS>::SPP * EpilogueShape<TW, TS>::stride(b->ntiles)) * sizeof(double);
+                              (size_t)groups * EpilogueShape<TW, TS>::SPP * EpilogueShape<TW, TS>::stride(logical_tiles(b->ntiles))) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "multi sweep needs %zu B of LDS", lds);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_multi<NTW, TS, CH, TW, ND>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -876,7 +876,7 @@ int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const u
         sa.sample_ll_dla = mb.sll_dla;
         sa.sample_ll_lls = mb.sll_lls;
         sa.ll_no_dla = mb.ll_no;
-        rc = b->k <= 20 ? launch_sweep_multi<16, 1, 4, 14>(c, b, sa) : launch_sweep_multi<14, 4, 1, 52>(c, b, sa);
+        rc = b->k <= 20 ? launch_sweep_multi<14, 1, 4, 13>(c, b, sa) : launch_sweep_multi<14, 4, 1, 52>(c, b, sa);
         if (rc) return rc;
       }
       // evidence, MAP, early-exit flags for the quasars of this sub-batch

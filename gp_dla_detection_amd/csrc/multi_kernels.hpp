@@ -125,7 +125,8 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   extern __shared__ double smem[];
   constexpr int GROUPS = kSweepWaves / TS;
   constexpr int NT = NTW * TS;
-  constexpr int RD = NT * 64 + 32;
+  constexpr int RD = NT * 64 + record_extras(NT);
+  constexpr bool kCompact = tiles_compact(NT);
   const int64_t xj = blockIdx.x >> 3;
   const int64_t ql = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
   const int bq = (int)(xj % a.blocks_per_quasar);
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
 #pragma unroll
   for (int c = 0; c < NTW; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
   double quad_sum = 0.0, dprod = 1.0;
+  double xw[kXW] = {0.0, 0.0}, xu[kXU] = {0.0, 0.0, 0.0, 0.0};  // compact class: columns kept off the MFMA
   int dexp = 0;
   const int tile0 = role * NTW;
 
@@ -188,9 +190,14 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   if (nchunks > 1) issue_chunk(1);
 
   double w_cur, u_cur, bop[NTW];
+  double xpr[kXW] = {0.0, 0.0}, upr[kXU] = {0.0, 0.0, 0.0, 0.0};  // compact class: this step's VALU columns
 #define GPDLA_MPREP(rec, absorb_in)                                                       \
   {                                                                                       \
     const double *extra_ = (rec) + NT * 64;                                               \
+    if (kCompact) {                                                                       \
+      _Pragma("unroll") for (int x = 0; x < kXW; ++x) xpr[x] = extra_[24 + 2 * jj + x];   \
+      _Pragma("unroll") for (int x = 0; x < kXU; ++x) upr[x] = extra_[32 + 4 * jj + x];   \
+    }                                                                                     \
     const double absorb_ = (absorb_in);                                                   \
     const double py_ = extra_[4 * jj], pmu_ = extra_[4 * jj + 1], pom_ = extra_[4 * jj + 2], \
                  pnu_ = extra_[4 * jj + 3];                                               \
@@ -227,6 +234,12 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
       const double aop = TS == 1 ? (cc < TW ? wa : ua) : (cc < NTW - kTail ? wa : a_tail);
       acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[cc], acc[cc], 0, 0, 0);
     }
+    if (kCompact) {
+#pragma unroll
+      for (int x = 0; x < kXW; ++x) xw[x] = fma(wa, xpr[x], xw[x]);
+#pragma unroll
+      for (int x = 0; x < kXU; ++x) xu[x] = fma(ua, upr[x], xu[x]);
+    }
     GPDLA_MPREP(rec, a_next)
   }
 #undef GPDLA_MPREP
@@ -236,14 +249,26 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   quad_sum += __shfl_xor(quad_sum, 32);
   logd_sum += __shfl_xor(logd_sum, 16);
   logd_sum += __shfl_xor(logd_sum, 32);
+  if (kCompact) {
+#pragma unroll
+    for (int x = 0; x < kXW; ++x) {
+      xw[x] += __shfl_xor(xw[x], 16);
+      xw[x] += __shfl_xor(xw[x], 32);
+    }
+#pragma unroll
+    for (int x = 0; x < kXU; ++x) {
+      xu[x] += __shfl_xor(xu[x], 16);
+      xu[x] += __shfl_xor(xu[x], 32);
+    }
+  }
 
   using ES = EpilogueShape<TW, TS>;
-  double *Eg = stage + (size_t)group * ES::SPP * ES::stride(NT);
+  double *Eg = stage + (size_t)group * ES::SPP * ES::stride(logical_tiles(NT));
 #pragma unroll
   for (int p = 0; p < ES::PASSES; ++p) {
     int sigma;
     bool writer;
-    const double ll = factor_pass<double, NTW, TS, TW>(acc, p, Eg, lane, role, tile0, a.k, quad_sum,
+    const double ll = factor_pass<double, NTW, TS, TW>(acc, xw, xu, p, Eg, lane, role, tile0, a.k, quad_sum,
                                                        logd_sum, m.n_kept, &sigma, &writer);
     const int64_t slot_s = slot0 + sigma;
     if (writer) {

@@ -45,6 +45,8 @@ template <> struct Mat<double> {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ int sample_of(int jj, int r) { return jj + 4 * r; }
+  static __device__ __forceinline__ int jj_of(int sample) { return sample & 3; }
+  static __device__ __forceinline__ int reg_of(int sample) { return sample >> 2; }
 };
 template <> struct Mat<float> {
   using acc_t = f4;
@@ -52,6 +54,8 @@ template <> struct Mat<float> {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   static __device__ __forceinline__ int sample_of(int jj, int r) { return 4 * jj + r; }
+  static __device__ __forceinline__ int jj_of(int sample) { return sample >> 2; }
+  static __device__ __forceinline__ int reg_of(int sample) { return sample & 3; }
 };
 
 constexpr int kMaxLines = 31;
@@ -303,6 +307,9 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
 //   [+16, +20)       padded wavelengths 4(t+3) .. 4(t+3)+3 (the raw profile runs three steps ahead)
 // Record `steps` (one past the last K-step) is neutral: zero tiles, (y, mu, omega2, nu) = (0,0,0,1).
 //   [+20, +32)       unused (keeps records 16-byte granular and 256-byte aligned)
+// compact class only (record_extras == 48):
+//   [+24, +32)       vech columns 208, 209 of pixels 4t .. 4t+3 (pixel jj at +24 + 2 jj)
+//   [+32, +48)       m columns 16 .. 19 of pixels 4t .. 4t+3   (pixel jj at +32 + 4 jj)
 // ------------------------------------------------------------------------------------------
 struct BuildRecordsArgs {
   const QuasarMeta *meta;
@@ -315,9 +322,20 @@ struct BuildRecordsArgs {
   int32_t f32_tiles;      // 1: tiles stored as float (the fp32-contraction study), 0: double
 };
 
-// doubles per record: tiles (64 elements each, as double or float) + 32 doubles of extras
-__host__ __device__ __forceinline__ int record_doubles(int ntiles, int f32_tiles) {
-  return ntiles * (f32_tiles ? 32 : 64) + 32;
+// Tile classes.  k <= 40: ntiles = 52 w-tiles + 4 u-tiles.  k <= 20 ("compact", ntiles == 14): 13
+// FULL w-tiles (vech columns 0..207) + 1 full u-tile (m columns 0..15) on the matrix cores; the
+// remaining 2 vech columns (208, 209) and 4 m columns (16..19) would each occupy a tile that is
+// 7/8 resp. 3/4 empty -- 128 of the 1024 MFMA cycles of a K-step -- and are accumulated with 6
+// FMAs per lane and K-step instead (kXW / kXU, operands in the record's extras).
+constexpr int kCompactTiles = 14, kXW = 2, kXU = 4, kXWColumn = 208, kXUColumn = 16;
+__host__ __device__ constexpr bool tiles_compact(int ntiles) { return ntiles == kCompactTiles; }
+// doubles of per-step extras behind the tiles of a record
+__host__ __device__ constexpr int record_extras(int ntiles) { return tiles_compact(ntiles) ? 48 : 32; }
+// tiles' worth of columns a sample's [vech(B) | v] occupies in the epilogue's LDS rows
+__host__ __device__ constexpr int logical_tiles(int ntiles) { return tiles_compact(ntiles) ? 16 : ntiles; }
+// doubles per record: tiles (64 elements each, as double or float) + the extras
+__host__ __device__ constexpr int record_doubles(int ntiles, int f32_tiles) {
+  return ntiles * (f32_tiles ? 32 : 64) + record_extras(ntiles);
 }
 
 __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
@@ -325,7 +343,8 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
   const int bq = blockIdx.x % a.blocks_per_quasar;
   const QuasarMeta m = a.meta[q];
   const int RD = record_doubles(a.ntiles, a.f32_tiles);
-  const int per_rec = a.ntiles * 64 + 32;  // logical elements per record
+  const int xtra = record_extras(a.ntiles);
+  const int per_rec = a.ntiles * 64 + xtra;  // logical elements per record
   const int64_t total = (int64_t)(m.steps + 1) * per_rec;
   const int ncol_w = a.k * (a.k + 1) / 2;
   const int n_pad = m.n_u + 6;
@@ -365,8 +384,18 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
         int P = 4 * (step + 3) + (r2 - 16);
         if (P > n_pad - 1) P = n_pad - 1;
         v = a.lam_pad[m.lam_off + P];
+      } else if (r2 >= 24 && xtra > 32) {  // compact class: the columns kept off the matrix cores
+        const bool is_w = r2 < 32;
+        const int jj = is_w ? (r2 - 24) >> 1 : (r2 - 32) >> 2;
+        const int x = is_w ? (r2 - 24) & 1 : (r2 - 32) & 3;
+        const double *row = a.Mi + (m.pix_off + 4 * (int64_t)step + jj) * a.k;
+        if (is_w) {  // vech index 208 + x = (19, 18 + x)
+          if (kXWColumn + x < ncol_w) v = row[19] * row[18 + x];
+        } else if (kXUColumn + x < a.k) {
+          v = row[kXUColumn + x];
+        }
       }
-      rec[RD - 32 + r2] = v;
+      rec[RD - xtra + r2] = v;
     }
   }
 }
@@ -681,14 +710,18 @@ template <int TW, int TS> struct EpilogueShape {
 // hold, in register r, the 16*NT columns of sample sample_of(jj, r)) to LDS and factor them.
 // Returns the sample's log-likelihood; *sigma_out = its index among the wave's 16, *writer = this
 // lane is the one that stores it.
+// xw / xu: the compact class's columns accumulated off the matrix cores (sample s = lane & 15 of
+// the wave, already summed over the four pixel phases); ignored otherwise.
 template <typename T, int NTW, int TS, int TW, typename ACC>
-__device__ __forceinline__ double factor_pass(const ACC (&acc)[NTW], int p, double *Eg, int lane,
+__device__ __forceinline__ double factor_pass(const ACC (&acc)[NTW], const double (&xw)[kXW],
+                                              const double (&xu)[kXU], int p, double *Eg, int lane,
                                               int role, int tile0, int k, double quad_sum,
                                               double logd_sum, int n_kept, int *sigma_out,
                                               bool *writer) {
   using ES = EpilogueShape<TW, TS>;
-  constexpr int voff = TW * 16;
-  constexpr int ncols = ES::stride(NTW * TS);
+  constexpr bool compact = tiles_compact(NTW * TS);
+  constexpr int voff = (TW + (compact ? 1 : 0)) * 16;  // v behind the vech columns (210 <= 224 when compact)
+  constexpr int ncols = ES::stride(logical_tiles(NTW * TS));
   const int s = lane & 15, jj = lane >> 4;
   const int half = ES::RPP == 2 ? (s >> 3) : 0;
   const int sigma = Mat<T>::sample_of(jj, ES::RPP * p + half);
@@ -698,10 +731,24 @@ __device__ __forceinline__ double factor_pass(const ACC (&acc)[NTW], int p, doub
   double *e = Eg + (size_t)(jj * ES::RPP) * ncols;
   if (TS > 1) __syncthreads();
 #pragma unroll
-  for (int cc = 0; cc < NTW; ++cc)
+  for (int cc = 0; cc < NTW; ++cc) {
+    const int tile = tile0 + cc;
+    const int col0 = tile < TW ? tile * 16 : voff + (tile - TW) * 16;  // w-tiles, then u-tiles at voff
 #pragma unroll
-    for (int h = 0; h < ES::RPP; ++h)
-      e[h * ncols + (tile0 + cc) * 16 + s] = (double)acc[cc][ES::RPP * p + h];
+    for (int h = 0; h < ES::RPP; ++h) e[h * ncols + col0 + s] = (double)acc[cc][ES::RPP * p + h];
+  }
+  if (compact) {
+    // lane (s, jj = 0) holds sample s of the wave; it is factored in pass reg/RPP from the LDS row
+    // of lane group jj_of(s), half reg % RPP
+    const int r = Mat<T>::reg_of(s);
+    if (jj == 0 && r / ES::RPP == p) {
+      double *es = Eg + (size_t)(Mat<T>::jj_of(s) * ES::RPP + r % ES::RPP) * ncols;
+#pragma unroll
+      for (int x = 0; x < kXW; ++x) es[kXWColumn + x] = xw[x];
+#pragma unroll
+      for (int x = 0; x < kXU; ++x) es[voff + kXUColumn + x] = xu[x];
+    }
+  }
   if (TS > 1) __syncthreads();
   else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -862,7 +909,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   constexpr int GROUPS = WAVES / TS;  // sample groups per block
   constexpr int NT = NTW * TS;
   constexpr int TD = 64 * (int)sizeof(T) / 8;  // doubles occupied by one 64-element tile
-  constexpr int RD = NT * TD + 32;
+  constexpr int RD = NT * TD + record_extras(NT);
+  constexpr bool kCompact = tiles_compact(NT);  // 13 + 1 tiles on the matrix cores, 2 + 4 columns on the VALU
   using acc_t = typename Mat<T>::acc_t;
   const int64_t xj = blockIdx.x >> 3;
   const int64_t q = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
@@ -955,6 +1003,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #pragma unroll
   for (int c = 0; c < NTW; ++c) acc[c] = acc_t{0, 0, 0, 0};
   double quad_sum = 0.0, dprod = 1.0;
+  double xw[kXW] = {0.0, 0.0}, xu[kXU] = {0.0, 0.0, 0.0, 0.0};  // compact class: columns kept off the MFMA
   int dexp = 0;
   const int tile0 = role * NTW;
   const int nw = TS == 1 ? TW : max(0, min(NTW, TW - tile0));  // w-tiles of this wave
@@ -1102,6 +1151,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
           acc[cc] = Mat<T>::mfma(aop, bop[cc], acc[cc]);
         }
 #endif
+        if (kCompact) {  // vech columns 208, 209 and m columns 16..19 of this lane's pixel: 6 FMAs
+          const double *xp = extra + 24 + 2 * jj, *up = extra + 32 + 4 * jj;
+#pragma unroll
+          for (int x = 0; x < kXW; ++x) xw[x] = fma(w, xp[x], xw[x]);
+#pragma unroll
+          for (int x = 0; x < kXU; ++x) xu[x] = fma(u, up[x], xu[x]);
+        }
         GPDLA_ST(3)  // MFMA burst (issue)
       }
     }
@@ -1121,17 +1177,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   quad_sum += __shfl_xor(quad_sum, 32);
   logd_sum += __shfl_xor(logd_sum, 16);
   logd_sum += __shfl_xor(logd_sum, 32);
+  if (kCompact) {
+#pragma unroll
+    for (int x = 0; x < kXW; ++x) {
+      xw[x] += __shfl_xor(xw[x], 16);
+      xw[x] += __shfl_xor(xw[x], 32);
+    }
+#pragma unroll
+    for (int x = 0; x < kXU; ++x) {
+      xu[x] += __shfl_xor(xu[x], 16);
+      xu[x] += __shfl_xor(xu[x], 32);
+    }
+  }
 
 #undef GPDLA_RAW_ACCURATE
   // ---- epilogue: factor_pass over the MFMA result registers ------------------------------------
   using ES = EpilogueShape<TW, TS>;
-  double *Eg = stage + (size_t)group * ES::SPP * ES::stride(NT);  // [SPP samples][stride] of this group
+  double *Eg = stage + (size_t)group * ES::SPP * ES::stride(logical_tiles(NT));  // [SPP samples][stride] of this group
 #pragma unroll
   for (int p = 0; p < ES::PASSES; ++p) {
     int sigma;
     bool writer;
-    const double ll = factor_pass<T, NTW, TS, TW>(acc, p, Eg, lane, role, tile0, a.k, quad_sum, logd_sum,
-                                                  m.n_kept, &sigma, &writer);
+    const double ll = factor_pass<T, NTW, TS, TW>(acc, xw, xu, p, Eg, lane, role, tile0, a.k, quad_sum,
+                                                  logd_sum, m.n_kept, &sigma, &writer);
     const int64_t slot_s = slot0 + sigma;
     const int32_t sample_s = __shfl(sample, sigma + 16 * jj);
     if (writer) {
