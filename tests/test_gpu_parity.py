@@ -199,6 +199,19 @@ def test_ranks_between_the_tile_classes(oracle, k):
     assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL
 
 
+@pytest.mark.parametrize("k", [16, 17, 19])
+def test_ranks_around_the_off_mfma_columns(oracle, k):
+    """k <= 20 keeps vech columns 208, 209 and projection columns 16..19 on the VALU: k = 16 uses
+    none of them, 17 and 19 some of the projection columns only, 20 (everywhere else) all six."""
+    model = synthetic.make_model(k)
+    samples = synthetic.make_samples(48)
+    sp = synthetic.make_spectrum(90 + k, 287, model, mask_fraction=0.03)
+    out = run_gpu(model, samples, [sp])
+    ref = run_oracle(oracle, model, samples, sp)
+    assert abs(out["log_likelihoods_no_dla"][0] - ref["log_likelihood_no_dla"]) < TOL
+    assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL
+
+
 def test_small_rank_model(oracle):
     model = synthetic.make_model(5)
     samples = synthetic.make_samples(20)
