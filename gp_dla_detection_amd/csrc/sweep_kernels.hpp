@@ -1094,8 +1094,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         const T *bt = reinterpret_cast<const T *>(rec) + (size_t)tile0 * 64 + lane;
         T bop[NTW];
+#ifdef GPDLA_ABLATE_NOBFRAG
+#pragma unroll
+        for (int cc = 0; cc < NTW; ++cc) bop[cc] = (T)(lane + cc) * (T)lamP;  // timing experiment: no fragment reads
+        (void)bt;
+#else
 #pragma unroll
         for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
+#endif
         __builtin_amdgcn_sched_barrier(0);
         double raw = exp_table_end(es);
 #ifdef GPDLA_ABLATE_NOVOIGT
