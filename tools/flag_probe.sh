@@ -1,0 +1,13 @@
+#!/bin/bash
+# Diagnostic: time the sweep kernel built with different -D flag sets (run on the GPU box).
+# usage: tools/flag_probe.sh "<flags A>" "<flags B>" ...   (an empty string = the shipped build)
+set -e
+cd "$(dirname "$0")/.."
+SRC=gp_dla_detection_amd/csrc/gpdla.hip
+FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -Wno-inline-asm"
+mkdir -p /tmp/ablate gpurun_out
+for v in "$@"; do
+  hipcc $FLAGS $v $SRC -o /tmp/ablate/lib_flag.so 2>/dev/null
+  ms=$(GPDLA_LIB_PATH=/tmp/ablate/lib_flag.so python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --spectra ${GPDLA_PROBE_SPECTRA:-512} | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['roofline']['kernel_ms'])")
+  echo "flags '$v' kernel_ms=$ms" | tee -a gpurun_out/flag_probe.txt
+done
