@@ -310,7 +310,7 @@ def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None
         longest = max((np.asarray(s["wavelengths"]).size for s in spectra), default=1)
         per_quasar = (longest / 4 + 2) * (14 * 64 + 48) * 8  # bytes of step records (k <= 20)
         if model["M"].shape[1] > 20:
-            per_quasar *= 3.5
+            per_quasar *= 3.9  # (56 * 64 + 32) / (14 * 64 + 48)
         max_quasars_per_batch = max(1, int(64 * 2**30 / per_quasar))
     ctx = Context(device, p)
     parts = []
