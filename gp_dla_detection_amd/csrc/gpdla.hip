@@ -1100,7 +1100,7 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
   a.f = t->d_f;
   a.g = t->d_g;
   a.not_pd = t->d_flag;
-  const size_t lds = (size_t)(3 * G + 2 * k * k + 3 * k + 8) * sizeof(double);
+  const size_t lds = training_lds_doubles(G, k) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "training kernel needs %zu B of LDS", lds);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_training_loss),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

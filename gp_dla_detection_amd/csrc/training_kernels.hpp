@@ -31,7 +31,15 @@ struct TrainingArgs {
   int32_t *not_pd;        // set to 1 if some B is not positive definite (chol would throw, :42)
 };
 
-// dynamic LDS: dinv[G] | y[G] | kiy[G] | L[k*k] | Binv[k*k] | t[k] | z[k] | gvec[k] | red[8]
+// dynamic LDS: dinv[G] | y[G] | kiy[G] | L[k*k] | Binv[k*k] | t[k] | z[k] | gvec[k] | red[8] |
+//              stage[2 k kTrainChunkStride]  (rows of M for a chunk of pixels; see the B build and pass 3)
+constexpr int kTrainChunk = 128;        // pixels per staged chunk in the B build
+constexpr int kTrainChunkStride = 129;  // odd row stride: threads read different rows at the same pixel
+__host__ __device__ constexpr size_t training_lds_doubles(int64_t G, int k) {
+  // stage: B build 2 k kTrainChunkStride, pass 3 k * 256; the larger of the two
+  return (size_t)(3 * G + 2 * k * k + 3 * k + 8) +
+         (size_t)(2 * k * kTrainChunkStride > k * 256 ? 2 * k * kTrainChunkStride : k * 256);
+}
 __global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
   extern __shared__ double sm[];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
   const int64_t G = a.G;
   double *s_dinv = sm, *s_y = s_dinv + G, *s_kiy = s_y + G;
   double *s_L = s_kiy + G, *s_Binv = s_L + k * k, *s_t = s_Binv + k * k, *s_z = s_t + k,
-         *s_g = s_z + k, *s_red = s_g + k;
+         *s_g = s_z + k, *s_red = s_g + k, *s_stage = s_red + 8;
   const double *F = a.flux + (int64_t)q * G, *Z = a.lya_1pz + (int64_t)q * G,
                *V = a.noise + (int64_t)q * G;
   const double log_2pi = 1.83787706640934534;  // spectrum_loss.m:17
@@ -72,52 +80,117 @@ __global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
   logd = block_sum(logd);
   cnt = block_sum(cnt);
   if (cnt == 0.0) return;  // quasar with no valid pixel contributes nothing
+#if defined(GPDLA_TRAIN_STOP) && GPDLA_TRAIN_STOP == 1
+  return;  // timing experiment (tools/flag_probe.sh): stop before this phase
+#endif
   // ---- B = I + M' D^-1 M (lower triangle) and t = M' D^-1 y (:40-41) ----
+  // Thread el owns one entry (i, j) of the triangle (or one entry of t).  The pixel axis is walked
+  // in chunks staged through LDS -- rows of M and of D^-1 M, loaded coalesced -- instead of every
+  // thread streaming two columns of M from memory on its own.
   const int nb = k * (k + 1) / 2;
-  for (int e = tid; e < nb + k; e += 256) {
-    double acc = 0.0;
-    if (e < nb) {
-      int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-      while ((i + 1) * (i + 2) / 2 <= e) ++i;
-      while (i * (i + 1) / 2 > e) --i;
-      const int j = e - i * (i + 1) / 2;
-      const double *Mi = a.M + (int64_t)i * G, *Mj = a.M + (int64_t)j * G;
-      for (int64_t p = 0; p < G; ++p) acc = fma(Mi[p] * s_dinv[p], Mj[p], acc);
-      if (i == j) acc += 1.0;
-      s_L[i * k + j] = acc;
-    } else {
-      const int i = e - nb;
-      const double *Mi = a.M + (int64_t)i * G;
-      for (int64_t p = 0; p < G; ++p) acc = fma(Mi[p], s_dinv[p] * s_y[p], acc);
-      s_t[i] = acc;
+  constexpr int kSlots = (GPDLA_MAX_K * (GPDLA_MAX_K + 1) / 2 + GPDLA_MAX_K + 255) / 256;  // entries per thread
+  int bi[kSlots], bj[kSlots];
+#pragma unroll
+  for (int sl = 0; sl < kSlots; ++sl) {
+    const int el = tid + 256 * sl;
+    bi[sl] = bj[sl] = 0;
+    if (el < nb) {
+      int i = (int)((sqrt(8.0 * el + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= el) ++i;
+      while (i * (i + 1) / 2 > el) --i;
+      bi[sl] = i;
+      bj[sl] = el - i * (i + 1) / 2;
+    } else if (el < nb + k) {
+      bi[sl] = el - nb;
+    }
+  }
+  {
+    double *s_mc = s_stage, *s_wc = s_stage + (size_t)k * kTrainChunkStride;  // M and D^-1 M rows of the chunk
+    double acc[kSlots];
+#pragma unroll
+    for (int sl = 0; sl < kSlots; ++sl) acc[sl] = 0.0;
+    for (int64_t base = 0; base < G; base += kTrainChunk) {
+      const int len = (int)min((int64_t)kTrainChunk, G - base);
+      __syncthreads();  // previous chunk consumed
+      {  // all of this thread's loads of the chunk first (k/2 of them), then the LDS writes
+        constexpr int kLoads = GPDLA_MAX_K * kTrainChunk / 256;
+        double mv[kLoads];
+#pragma unroll
+        for (int u = 0; u < kLoads; ++u) {
+          const int idx = tid + 256 * u;
+          const int e = idx / kTrainChunk, pp = idx % kTrainChunk;
+          mv[u] = (e < k && pp < len) ? a.M[base + pp + (int64_t)e * G] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kLoads; ++u) {
+          const int idx = tid + 256 * u;
+          const int e = idx / kTrainChunk, pp = idx % kTrainChunk;
+          if (e < k) {
+            s_mc[e * kTrainChunkStride + pp] = mv[u];
+            s_wc[e * kTrainChunkStride + pp] = pp < len ? mv[u] * s_dinv[base + pp] : 0.0;
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sl = 0; sl < kSlots; ++sl) {
+        const int el = tid + 256 * sl;
+        if (el < nb) {
+          const double *wi = s_wc + bi[sl] * kTrainChunkStride, *mj = s_mc + bj[sl] * kTrainChunkStride;
+#pragma unroll 16
+          for (int pp = 0; pp < len; ++pp) acc[sl] = fma(wi[pp], mj[pp], acc[sl]);
+        } else if (el < nb + k) {
+          const double *wi = s_wc + bi[sl] * kTrainChunkStride;
+#pragma unroll 16
+          for (int pp = 0; pp < len; ++pp) acc[sl] = fma(wi[pp], s_y[base + pp], acc[sl]);
+        }
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < kSlots; ++sl) {
+      const int el = tid + 256 * sl;
+      if (el < nb) s_L[bi[sl] * k + bj[sl]] = bi[sl] == bj[sl] ? acc[sl] + 1.0 : acc[sl];
+      else if (el < nb + k) s_t[bi[sl]] = acc[sl];
     }
   }
   __syncthreads();
-  // ---- Cholesky B = L L' in place (lower), thread 0 (:42) ----
-  if (tid == 0) {
+#if defined(GPDLA_TRAIN_STOP) && GPDLA_TRAIN_STOP == 2
+  return;  // timing experiment (tools/flag_probe.sh): stop before this phase
+#endif
+  // ---- Cholesky B = L L' in place (lower) (:42): right-looking, lane i of wave 0 owns row i ----
+  if (wave == 0) {
     double logdiag = 0.0;
     bool pd = true;
-    for (int i = 0; i < k; ++i)
-      for (int j = 0; j <= i; ++j) {
-        double sum = s_L[i * k + j];
-        for (int mm = 0; mm < j; ++mm) sum = fma(-s_L[i * k + mm], s_L[j * k + mm], sum);
-        if (i == j) {
-          pd = pd && (sum > 0.0);
-          const double lii = sqrt(sum);
-          logdiag += log(lii);
-          s_L[i * k + i] = lii;
-        } else {
-          s_L[i * k + j] = sum / s_L[j * k + j];
-        }
+    for (int j = 0; j < k; ++j) {
+      const double djj = s_L[j * k + j];
+      pd = pd && (djj > 0.0);
+      const double ljj = sqrt(djj);
+      logdiag += log(ljj);
+      __builtin_amdgcn_wave_barrier();  // everyone has read the pivot before it is overwritten
+      if (lane == j) s_L[j * k + j] = ljj;
+      if (lane > j && lane < k) s_L[lane * k + j] /= ljj;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane > j && lane < k) {  // trailing update of this lane's row
+        const double lij = s_L[lane * k + j];
+        for (int c = j + 1; c <= lane; ++c) s_L[lane * k + c] = fma(-lij, s_L[c * k + j], s_L[lane * k + c]);
       }
-    s_red[4] = logdiag;
-    s_red[5] = pd ? 0.0 : 1.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+      s_red[4] = logdiag;
+      s_red[5] = pd ? 0.0 : 1.0;
+    }
   }
   __syncthreads();
   if (s_red[5] != 0.0) {
     if (tid == 0) *a.not_pd = 1;
     return;
   }
+#if defined(GPDLA_TRAIN_STOP) && GPDLA_TRAIN_STOP == 3
+  return;  // timing experiment (tools/flag_probe.sh): stop before this phase
+#endif
   // ---- B^-1 column by column (threads 0..k-1), z = B^-1 t (thread k) ----
   if (tid <= k) {
     double w[GPDLA_MAX_K];
@@ -137,6 +210,9 @@ __global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
     }
   }
   __syncthreads();
+#if defined(GPDLA_TRAIN_STOP) && GPDLA_TRAIN_STOP == 4
+  return;  // timing experiment (tools/flag_probe.sh): stop before this phase
+#endif
   // ---- pass 2: K^-1 y (:46), y' K^-1 y ----
   double quad = 0.0;
   for (int64_t p = tid; p < G; p += 256) {
@@ -155,19 +231,35 @@ __global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
     s_g[c] = acc;
   }
   __syncthreads();
+#if defined(GPDLA_TRAIN_STOP) && GPDLA_TRAIN_STOP == 5
+  return;  // timing experiment (tools/flag_probe.sh): stop before this phase
+#endif
   // ---- pass 3: gradients (:55-74) ----
+  // m_p' B^-1 for this thread's pixel: the row m_p is staged in LDS (column tid of s_mrow), so the
+  // k x k loop reads it with compile-time-free indices from LDS instead of a run-time indexed
+  // private array (which lands in scratch memory).
   double gc = 0.0, gt = 0.0, gb = 0.0;
-  for (int64_t p = tid; p < G; p += 256) {
-    const double dinv = s_dinv[p];
-    if (dinv == 0.0) continue;  // missing pixel
-    double mrow[GPDLA_MAX_K];
-    for (int c = 0; c < k; ++c) mrow[c] = a.M[p + (int64_t)c * G];
+  double *s_mrow = s_stage;  // [k][256]
+  __syncthreads();           // the B build's use of the stage region is long over; be explicit
+  for (int64_t base = 0; base < G; base += 256) {
+    const int64_t p = base + tid;
+    const double dinv = p < G ? s_dinv[p] : 0.0;
+    if (dinv == 0.0) continue;  // missing pixel (or past the end): no block-wide sync below
+    {  // this pixel's row of M: all loads in flight at once, then the LDS writes
+      double mv[GPDLA_MAX_K];
+#pragma unroll
+      for (int c = 0; c < GPDLA_MAX_K; ++c) mv[c] = c < k ? a.M[p + (int64_t)c * G] : 0.0;
+#pragma unroll
+      for (int c = 0; c < GPDLA_MAX_K; ++c)
+        if (c < k) s_mrow[c * 256 + tid] = mv[c];
+    }
     const double kiy = s_kiy[p];
     double mBm = 0.0;
     for (int c = 0; c < k; ++c) {
       double mb = 0.0;  // (m_p' B^-1)_c
-      for (int e = 0; e < k; ++e) mb = fma(mrow[e], s_Binv[e * k + c], mb);
-      mBm = fma(mb, mrow[c], mBm);
+#pragma unroll 4
+      for (int e = 0; e < k; ++e) mb = fma(s_mrow[e * 256 + tid], s_Binv[e * k + c], mb);
+      mBm = fma(mb, s_mrow[c * 256 + tid], mBm);
       const double dM = dinv * mb - kiy * s_g[c];                     // :55-56
       atomicAdd(a.g + p + (int64_t)c * G, dM);
     }

@@ -47,7 +47,9 @@ def test_oracle_threads_agree(oracle):
 @pytest.mark.gpu
 def test_gpu_objective_matches_oracle(oracle):
     from gp_dla_detection_amd import training
-    for (nq, G, k) in ((40, 64, 5), (64, 1217, 20)):
+    # (40 pixels: shorter than one staged chunk; 300: a ragged last chunk; k = 33, 40: several
+    # entries of B per thread)
+    for (nq, G, k) in ((40, 64, 5), (64, 1217, 20), (24, 300, 33), (16, 513, 40), (8, 40, 3)):
         x, F, L1, NV = training_problem(nq=nq, G=G, k=k, seed=k)
         f_ref, g_ref = oracle.objective(x, F, L1, NV)
         f, g = training.objective(x, F, L1, NV)
