@@ -1,0 +1,26 @@
+"""Randomised parity check of the sweep against the CPU oracle (run on the GPU box): random rank
+1..40, length, sample count and mask fraction; tolerance 1e-8 absolute as in tests/."""
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import gp_dla_detection_amd as gp
+from gp_dla_detection_amd import synthetic
+from oracle import oracle
+rng = np.random.default_rng(7)
+worst = 0.0
+for trial in range(24):
+    k = int(rng.integers(1, 41))
+    n = int(rng.integers(30, 700))
+    S = int(rng.integers(1, 90))
+    model = synthetic.make_model(k)
+    samples = synthetic.make_samples(S)
+    sp = synthetic.make_spectrum(2000 + trial, n, model, mask_fraction=float(rng.uniform(0, 0.2)))
+    out = gp.process_qsos(model, samples, [sp], log_priors=(np.array([-1.0]), np.array([-1.0])))
+    ref = oracle.process_spectrum(model, samples["offset_samples"], samples["nhi_samples"], sp["wavelengths"],
+                                  sp["flux"], sp["noise_variance"], sp["pixel_mask"], sp["z_qso"])
+    d = max(float(np.nanmax(np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]))),
+            abs(out["log_likelihoods_no_dla"][0] - ref["log_likelihood_no_dla"]))
+    worst = max(worst, d)
+    print(trial, k, n, S, f"{d:.2e}", flush=True)
+print("worst", worst)
+assert worst < 1e-8
