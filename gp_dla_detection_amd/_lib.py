@@ -61,7 +61,8 @@ class Config(C.Structure):
                 ("max_dlas", C.c_int32), ("num_forest_lines", C.c_int32),
                 ("min_z_separation", C.c_double), ("prev_tau_0", C.c_double),
                 ("prev_beta", C.c_double), ("rng_seed", C.c_uint64),
-                ("first_quasar_index", C.c_int64), ("contraction_precision", C.c_int32)]
+                ("first_quasar_index", C.c_int64), ("contraction_precision", C.c_int32),
+                ("multi_profile_bytes", C.c_int64)]
 
 
 class Results(C.Structure):
@@ -69,7 +70,7 @@ class Results(C.Structure):
                 ("sample_log_likelihoods_dla", _dp), ("log_likelihoods_dla", _dp),
                 ("log_posteriors_no_dla", _dp), ("log_posteriors_dla", _dp),
                 ("model_posteriors", _dp), ("p_no_dlas", _dp), ("p_dlas", _dp),
-                ("status", _i32p)]
+                ("status", _i32p), ("MAP_inds", _dp), ("MAP_z_dlas", _dp), ("MAP_log_nhis", _dp)]
 
 
 class ResultsMulti(C.Structure):
@@ -79,6 +80,14 @@ class ResultsMulti(C.Structure):
         "log_posteriors_no_dla", "log_posteriors_lls", "log_posteriors_dla", "model_posteriors",
         "p_no_dlas", "p_lls", "p_dlas", "MAP_z_dlas", "MAP_log_nhis", "MAP_inds")] + [
         ("base_sample_inds", _u32p), ("status", _i32p)]
+
+
+SUMMARY_COLS = 15  # GPDLA_SUMMARY_COLS
+
+
+def summary_cols_multi(max_dlas: int) -> int:
+    """GPDLA_SUMMARY_COLS_MULTI"""
+    return 14 + 4 * max_dlas + 3 * max_dlas * max_dlas
 
 
 #: every symbol include/gpdla.h declares: (name, restype, argtypes)
@@ -107,11 +116,17 @@ SYMBOLS = [
     ("gpdla_context_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("gpdla_process_batch_multi", C.c_int, [C.POINTER(Model), C.POINTER(Samples), C.POINTER(Spectra),
                                             _u32p, C.POINTER(Config), C.POINTER(ResultsMulti), C.c_int]),
+    ("gpdla_batch_process_multi", C.c_int, [C.c_void_p, C.c_void_p, _u32p]),
+    ("gpdla_batch_download_multi", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ResultsMulti)]),
+    ("gpdla_batch_summary_multi_device_ptr", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _i64p, _i32p]),
+    ("gpdla_batch_samples_multi_device_ptr", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p),
+                                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("gpdla_training_create", C.c_int, [C.c_int, C.c_int64, C.c_int64, _dp, _dp, _dp,
                                         C.POINTER(C.c_void_p)]),
     ("gpdla_training_objective", C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
     ("gpdla_training_destroy", None, [C.c_void_p]),
     ("gpdla_debug_near_poly", C.c_int, [C.c_int, C.c_double, _dp, _dp]),
+    ("gpdla_debug_philox4x32_10", None, [_u32p, _u32p, _u32p]),
 ]
 
 _lib = None
@@ -119,9 +134,9 @@ _lib = None
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/gpdla.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("gpdla.hip", "sweep_kernels.hpp", "multi_kernels.hpp",
-                                            "training_kernels.hpp", "faddeeva.hpp")]
-    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("gpdla.h", "gpdla_lyman_series.h")]
+    import glob
+    srcs = (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))
+            + glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
             return LIB_PATH

@@ -42,7 +42,7 @@ def _config(params: Parameters) -> _lib.Config:
                  "max_z_cut", "min_z_cut", "width", "num_lines"):
         setattr(cfg, name, getattr(params, name))
     for name in ("max_dlas", "num_forest_lines", "min_z_separation", "prev_tau_0", "prev_beta",
-                 "rng_seed", "first_quasar_index", "contraction_precision"):
+                 "rng_seed", "first_quasar_index", "contraction_precision", "multi_profile_bytes"):
         if hasattr(params, name):
             setattr(cfg, name, getattr(params, name))
     return cfg
@@ -187,8 +187,16 @@ class Context:
     def synchronize(self):
         _lib.check(self.lib.gpdla_context_synchronize(self._h))
 
-    def upload(self, spectra, log_priors_no_dla, log_priors_dla) -> "Batch":
-        return Batch(self, spectra, log_priors_no_dla, log_priors_dla)
+    def upload(self, spectra, log_priors_no_dla, log_priors_dla, log_priors_lls=None) -> "Batch":
+        """Spectra + priors to HBM.  With ``log_priors_lls`` the batch is a multi-DLA batch
+        (``log_priors_dla`` is then [nq, max_dlas]) and is swept with :meth:`Batch.process_multi`."""
+        return Batch(self, spectra, log_priors_no_dla, log_priors_dla, log_priors_lls)
+
+    def set_params(self, params: Parameters):
+        """Replace the configuration (e.g. ``first_quasar_index`` between shards)."""
+        self.params = params
+        cfg = _config(params)
+        _lib.check(self.lib.gpdla_context_set_config(self._h, C.byref(cfg)))
 
     def close(self):
         if self._h:
@@ -205,11 +213,12 @@ class Context:
 class Batch:
     """A CSR batch of spectra resident in HBM together with its result tables (gpdla_batch)."""
 
-    def __init__(self, ctx: Context, spectra, log_priors_no_dla, log_priors_dla):
+    def __init__(self, ctx: Context, spectra, log_priors_no_dla, log_priors_dla, log_priors_lls=None):
         self.ctx = ctx
         csr = spectra if isinstance(spectra, dict) else spectra_to_csr(spectra)
         self.num_quasars = csr["z_qsos"].size
         self.num_samples = ctx.num_samples
+        self.max_dlas = int(getattr(ctx.params, "max_dlas", 0)) if log_priors_lls is not None else 0
         keep = []
 
         def ptr(a, dt, ct):
@@ -217,17 +226,21 @@ class Batch:
             keep.append(a)
             return a.ctypes.data_as(C.POINTER(ct))
 
+        lp_dla = np.asarray(log_priors_dla, dtype=np.float64)
+        if self.max_dlas:
+            lp_dla = lp_dla.reshape(self.num_quasars, self.max_dlas)
         sp = _lib.Spectra(
             self.num_quasars, ptr(csr["offsets"], np.int64, C.c_int64),
             ptr(csr["wavelengths"], np.float64, C.c_double), ptr(csr["flux"], np.float64, C.c_double),
             ptr(csr["noise_variance"], np.float64, C.c_double),
             ptr(csr["pixel_mask"], np.uint8, C.c_uint8), ptr(csr["z_qsos"], np.float64, C.c_double),
-            ptr(log_priors_no_dla, np.float64, C.c_double),
-            ptr(log_priors_dla, np.float64, C.c_double), None)
+            ptr(log_priors_no_dla, np.float64, C.c_double), ptr(lp_dla, np.float64, C.c_double),
+            ptr(log_priors_lls, np.float64, C.c_double) if self.max_dlas else None)
         self._h = C.c_void_p()
         _lib.check(ctx.lib.gpdla_batch_upload(ctx._h, C.byref(sp), C.byref(self._h)))
         self.log_priors_no_dla = np.array(log_priors_no_dla, dtype=np.float64)
-        self.log_priors_dla = np.array(log_priors_dla, dtype=np.float64)
+        self.log_priors_dla = np.array(lp_dla, dtype=np.float64)
+        self.log_priors_lls = None if log_priors_lls is None else np.array(log_priors_lls, dtype=np.float64)
 
     def process(self):
         """Launch the sweep for every quasar of the batch (asynchronous on the context's stream)."""
@@ -239,6 +252,8 @@ class Batch:
         out = {name: np.full(nq, np.nan) for name in (
             "min_z_dlas", "max_z_dlas", "log_likelihoods_no_dla", "log_likelihoods_dla",
             "log_posteriors_no_dla", "log_posteriors_dla", "p_no_dlas", "p_dlas")}
+        for name in ("MAP_inds", "MAP_z_dlas", "MAP_log_nhis"):  # generate_ascii_catalog.m:73-80
+            out[name] = np.full(nq, np.nan)
         out["model_posteriors"] = np.full((nq, 2), np.nan)
         out["status"] = np.zeros(nq, dtype=np.int32)
         if with_samples:
@@ -254,12 +269,80 @@ class Batch:
         return out
 
     def summary_tensor(self):
-        """The [nq, 12] per-quasar summary table as a zero-copy torch tensor on this GPU."""
+        """The per-quasar summary table as a zero-copy torch tensor on this GPU: [nq, 15] for a
+        single-DLA batch, [nq, GPDLA_SUMMARY_COLS_MULTI(max_dlas)] (78 for max_dlas = 4) for a
+        multi-DLA batch.  This is the row a multi-GPU run all-gathers."""
         import torch
         p, n = C.c_void_p(), C.c_int64()
-        _lib.check(self.ctx.lib.gpdla_batch_summary_device_ptr(self._h, C.byref(p), C.byref(n)))
-        return torch.as_tensor(_DeviceArray(p.value, (n.value, 12), self),
+        if self.max_dlas:
+            cols = C.c_int32()
+            _lib.check(self.ctx.lib.gpdla_batch_summary_multi_device_ptr(self._h, C.byref(p), C.byref(n),
+                                                                         C.byref(cols)))
+            ncol = cols.value
+        else:
+            _lib.check(self.ctx.lib.gpdla_batch_summary_device_ptr(self._h, C.byref(p), C.byref(n)))
+            ncol = _lib.SUMMARY_COLS
+        return torch.as_tensor(_DeviceArray(p.value, (n.value, ncol), self),
                                device=f"cuda:{self.ctx.device}")
+
+    # ---- multi-DLA batch (process_qsos_multiple_dlas_meanflux.m:141-495) ----
+
+    def process_multi(self, base_sample_inds=None):
+        """Launch the multi-DLA driver for every quasar of the batch.  ``base_sample_inds``:
+        optional uint32 [nq, max_dlas-1, S], 1-based (0 = never drawn); omitted, the resampling
+        of :467-472 is drawn on the GPU."""
+        nq, md, S = self.num_quasars, self.max_dlas, self.num_samples
+        base_ptr = None
+        if base_sample_inds is not None:
+            base = np.ascontiguousarray(base_sample_inds, dtype=np.uint32)
+            if base.shape != (nq, md - 1, S):
+                raise _lib.GpdlaError(-1, f"base_sample_inds must be [nq, max_dlas-1, S], got {base.shape}")
+            base_ptr = base.ctypes.data_as(C.POINTER(C.c_uint32))
+        _lib.check(self.ctx.lib.gpdla_batch_process_multi(self.ctx._h, self._h, base_ptr))
+
+    def download_multi(self, with_samples: bool = True) -> dict:
+        """Results under the variable names the multi-DLA script saves (:498-510); 3-D arrays are
+        ``sample_log_likelihoods_dla [nq, max_dlas, S]`` and ``MAP_* [nq, model, slot]``."""
+        nq, md, S = self.num_quasars, self.max_dlas, self.num_samples
+        out = {
+            "min_z_dlas": np.full(nq, np.nan), "max_z_dlas": np.full(nq, np.nan),
+            "log_likelihoods_no_dla": np.full(nq, np.nan),
+            "log_likelihoods_dla": np.full((nq, md), np.nan), "log_likelihoods_lls": np.full(nq, np.nan),
+            "log_posteriors_no_dla": np.full(nq, np.nan), "log_posteriors_lls": np.full(nq, np.nan),
+            "log_posteriors_dla": np.full((nq, md), np.nan),
+            "model_posteriors": np.full((nq, 2 + md), np.nan),
+            "p_no_dlas": np.full(nq, np.nan), "p_lls": np.full(nq, np.nan), "p_dlas": np.full(nq, np.nan),
+            "MAP_z_dlas": np.full((nq, md, md), np.nan), "MAP_log_nhis": np.full((nq, md, md), np.nan),
+            "MAP_inds": np.full((nq, md, md), np.nan),
+            "status": np.zeros(nq, dtype=np.int32),
+        }
+        if with_samples:
+            out["sample_log_likelihoods_dla"] = np.full((nq, md, S), np.nan)
+            out["sample_log_likelihoods_lls"] = np.full((nq, S), np.nan)
+            out["base_sample_inds"] = np.zeros((nq, max(md - 1, 1), S), dtype=np.uint32)
+        r = _lib.ResultsMulti()
+        for name, _ in _lib.ResultsMulti._fields_:
+            if name in out:
+                ct = {"status": C.c_int32, "base_sample_inds": C.c_uint32}.get(name, C.c_double)
+                setattr(r, name, out[name].ctypes.data_as(C.POINTER(ct)))
+        _lib.check(self.ctx.lib.gpdla_batch_download_multi(self.ctx._h, self._h, C.byref(r)))
+        out["log_priors_no_dla"], out["log_priors_lls"], out["log_priors_dla"] = (
+            self.log_priors_no_dla, self.log_priors_lls, self.log_priors_dla)
+        out["all_exceptions"] = np.where(out["status"] == 1, 1.0, np.nan)  # multi :139, :232
+        if with_samples and md > 1:
+            out["base_sample_inds"] = out["base_sample_inds"][:, : md - 1]
+        return out
+
+    def samples_multi_tensors(self):
+        """(sample_log_likelihoods_dla [nq, max_dlas, S], sample_log_likelihoods_lls [nq, S]) of a
+        multi-DLA batch as zero-copy torch tensors on this GPU."""
+        import torch
+        a, b = C.c_void_p(), C.c_void_p()
+        _lib.check(self.ctx.lib.gpdla_batch_samples_multi_device_ptr(self._h, C.byref(a), C.byref(b), None))
+        nq, md, S = self.num_quasars, self.max_dlas, self.num_samples
+        dev = f"cuda:{self.ctx.device}"
+        return (torch.as_tensor(_DeviceArray(a.value, (nq, md, S), self), device=dev),
+                torch.as_tensor(_DeviceArray(b.value, (nq, S), self), device=dev))
 
     def samples_tensor(self):
         """sample_log_likelihoods_dla [nq, S] as a zero-copy torch tensor on this GPU."""
@@ -362,80 +445,56 @@ def dla_existence_prior_multi(prior_z_qsos, prior_dla_ind, z_qsos, Z_lls: float,
 
 def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log_priors,
                                         params: MultiParameters | None = None,
-                                        base_sample_inds=None, device: int = 0) -> dict:
+                                        base_sample_inds=None, device: int = 0,
+                                        max_quasars_per_batch: int | None = None) -> dict:
     """The multi-DLA driver (multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-510).
 
     ``samples`` additionally carries ``log_nhi_samples`` and ``lls_nhi_samples``
     (set_lls_parameters.m:59-63).  ``log_priors = (no_dla [nq], lls [nq], dla [nq, max_dlas])`` as
     returned by :func:`dla_existence_prior_multi`.  ``base_sample_inds``: optional uint32
     ``[nq, max_dlas-1, S]``, 1-based (the reference's saved variable, :476, transposed to
-    quasar-slowest); when omitted the resampling of :467-472 is drawn on the GPU (Philox4x32-10,
-    ``params.rng_seed``).  Returns the variables the script saves (:498-510); 3-D arrays are
+    quasar-slowest; rows the reference left zero after its early exit make the samples that
+    would consume them NaN); when omitted the resampling of :467-472 is drawn on the GPU
+    (Philox4x32-10, ``params.rng_seed``, keyed by ``params.first_quasar_index`` + position, so
+    batches and shards of one run draw what the whole run would).  Quasars are independent, so a
+    long list is swept in HBM-resident batches of at most ``max_quasars_per_batch``.
+    Returns the variables the script saves (:498-510); 3-D arrays are
     ``sample_log_likelihoods_dla [nq, max_dlas, S]`` and ``MAP_* [nq, model, slot]``."""
-    lib = _lib.load()
+    from dataclasses import replace
     p = params or MultiParameters()
-    csr = spectra if isinstance(spectra, dict) else spectra_to_csr(spectra)
-    nq, md = csr["z_qsos"].size, p.max_dlas
-    keep = []
-
-    def ptr(a, dt, ct):
-        a = np.ascontiguousarray(a, dtype=dt)
-        keep.append(a)
-        return a.ctypes.data_as(C.POINTER(ct))
-
-    rw, rwp = _f64(model["rest_wavelengths"])
-    mu, mup = _f64(model["mu"])
-    Mf = np.asfortranarray(model["M"], dtype=np.float64)
-    lo, lop = _f64(model["log_omega"])
-    m = _lib.Model(rw.size, Mf.shape[1], rwp, mup, Mf.ctypes.data_as(_dp), lop,
-                   float(model["log_c_0"]), float(model["log_tau_0"]), float(model["log_beta"]))
+    spectra = list(spectra) if not isinstance(spectra, dict) else spectra
+    if isinstance(spectra, dict):  # CSR in: one batch
+        nq = spectra["z_qsos"].size
+        blocks = [(0, nq, spectra)]
+    else:
+        nq = len(spectra)
+        if max_quasars_per_batch is None:
+            max_quasars_per_batch = max(1, nq)
+        blocks = [(lo, min(lo + max_quasars_per_batch, nq), spectra[lo:lo + max_quasars_per_batch])
+                  for lo in range(0, nq, max_quasars_per_batch)]
+    md = p.max_dlas
     S = np.asarray(samples["offset_samples"]).size
-    sm = _lib.Samples(S, ptr(samples["offset_samples"], np.float64, C.c_double),
-                      ptr(samples["log_nhi_samples"], np.float64, C.c_double),
-                      ptr(samples["nhi_samples"], np.float64, C.c_double),
-                      ptr(samples["lls_nhi_samples"], np.float64, C.c_double))
-    lp_no, lp_lls, lp_dla = log_priors
-    sp = _lib.Spectra(nq, ptr(csr["offsets"], np.int64, C.c_int64),
-                      ptr(csr["wavelengths"], np.float64, C.c_double),
-                      ptr(csr["flux"], np.float64, C.c_double),
-                      ptr(csr["noise_variance"], np.float64, C.c_double),
-                      ptr(csr["pixel_mask"], np.uint8, C.c_uint8),
-                      ptr(csr["z_qsos"], np.float64, C.c_double),
-                      ptr(lp_no, np.float64, C.c_double),
-                      ptr(np.asarray(lp_dla).reshape(nq, md), np.float64, C.c_double),
-                      ptr(lp_lls, np.float64, C.c_double))
-    cfg = _config(p)
-    out = {
-        "min_z_dlas": np.full(nq, np.nan), "max_z_dlas": np.full(nq, np.nan),
-        "log_likelihoods_no_dla": np.full(nq, np.nan),
-        "sample_log_likelihoods_dla": np.full((nq, md, S), np.nan),
-        "sample_log_likelihoods_lls": np.full((nq, S), np.nan),
-        "log_likelihoods_dla": np.full((nq, md), np.nan), "log_likelihoods_lls": np.full(nq, np.nan),
-        "log_posteriors_no_dla": np.full(nq, np.nan), "log_posteriors_lls": np.full(nq, np.nan),
-        "log_posteriors_dla": np.full((nq, md), np.nan),
-        "model_posteriors": np.full((nq, 2 + md), np.nan),
-        "p_no_dlas": np.full(nq, np.nan), "p_lls": np.full(nq, np.nan), "p_dlas": np.full(nq, np.nan),
-        "MAP_z_dlas": np.full((nq, md, md), np.nan), "MAP_log_nhis": np.full((nq, md, md), np.nan),
-        "MAP_inds": np.full((nq, md, md), np.nan),
-        "base_sample_inds": np.zeros((nq, max(md - 1, 1), S), dtype=np.uint32),
-        "status": np.zeros(nq, dtype=np.int32),
-    }
-    r = _lib.ResultsMulti()
-    for name, _ in _lib.ResultsMulti._fields_:
-        ct = {"status": C.c_int32, "base_sample_inds": C.c_uint32}.get(name, C.c_double)
-        setattr(r, name, out[name].ctypes.data_as(C.POINTER(ct)))
-    base_ptr = None
+    lp_no, lp_lls, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
+    lp_dla = lp_dla.reshape(nq, md)
     if base_sample_inds is not None:
-        base = np.ascontiguousarray(base_sample_inds, dtype=np.uint32)
-        if base.shape != (nq, md - 1, S):
-            raise _lib.GpdlaError(-1, f"base_sample_inds must be [nq, max_dlas-1, S], got {base.shape}")
-        keep.append(base)
-        base_ptr = base.ctypes.data_as(C.POINTER(C.c_uint32))
-    _lib.check(lib.gpdla_process_batch_multi(C.byref(m), C.byref(sm), C.byref(sp), base_ptr,
-                                             C.byref(cfg), C.byref(r), int(device)))
-    out["log_priors_no_dla"], out["log_priors_lls"], out["log_priors_dla"] = (
-        np.asarray(lp_no), np.asarray(lp_lls), np.asarray(lp_dla).reshape(nq, md))
-    out["all_exceptions"] = np.where(out["status"] == 1, 1.0, np.nan)  # multi :139, :232
-    if md > 1:
-        out["base_sample_inds"] = out["base_sample_inds"][:, : md - 1]
-    return out
+        base_sample_inds = np.ascontiguousarray(base_sample_inds, dtype=np.uint32)
+        if base_sample_inds.shape != (nq, md - 1, S):
+            raise _lib.GpdlaError(-1, "base_sample_inds must be [nq, max_dlas-1, S], got "
+                                  f"{base_sample_inds.shape}")
+    ctx = Context(device, p)
+    parts = []
+    try:
+        ctx.set_model(model)
+        ctx.set_samples(samples)
+        for lo, hi, block in blocks:
+            if lo:
+                ctx.set_params(replace(p, first_quasar_index=p.first_quasar_index + lo))
+            batch = ctx.upload(block, lp_no[lo:hi], lp_dla[lo:hi], lp_lls[lo:hi])
+            try:
+                batch.process_multi(None if base_sample_inds is None else base_sample_inds[lo:hi])
+                parts.append(batch.download_multi())
+            finally:
+                batch.close()
+    finally:
+        ctx.close()
+    return {key: np.concatenate([part[key] for part in parts], axis=0) for key in parts[0]} if parts else {}

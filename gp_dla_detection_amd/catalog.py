@@ -9,10 +9,11 @@ import re
 import numpy as np
 
 
-def map_estimates(results: dict, samples: dict):
-    """MAP (z_DLA, log10 N_HI) per quasar: generate_ascii_catalog.m:73-80 -- the sample with the
-    largest log-likelihood (``nanmax``; first index on ties), mapped to a redshift with the
-    quasar's own search range (process_qsos.m:162-164)."""
+def map_estimates_host(results: dict, samples: dict):
+    """MAP (z_DLA, log10 N_HI, 0-based index) per quasar recomputed on the host from the full
+    sample table: generate_ascii_catalog.m:73-80 -- the sample with the largest log-likelihood
+    (``nanmax``; first index on ties), mapped to a redshift with the quasar's own search range
+    (process_qsos.m:162-164).  Needs ``sample_log_likelihoods_dla`` (80 KB per quasar)."""
     sll = np.asarray(results["sample_log_likelihoods_dla"])
     nq = sll.shape[0]
     map_ind = np.zeros(nq, dtype=np.int64)
@@ -21,6 +22,18 @@ def map_estimates(results: dict, samples: dict):
     off = np.asarray(samples["offset_samples"])[map_ind]
     z = results["min_z_dlas"] + (results["max_z_dlas"] - results["min_z_dlas"]) * off
     return z, np.asarray(samples["log_nhi_samples"])[map_ind], map_ind
+
+
+def map_estimates(results: dict, samples: dict | None = None):
+    """MAP (z_DLA, log10 N_HI, 0-based index) per quasar.  The evidence kernel already finds them
+    while it walks the sample table on the GPU (summary columns MAP_inds / MAP_z_dlas /
+    MAP_log_nhis), so results that carry those columns need no 80 KB-per-quasar table on the host;
+    older result dicts fall back to :func:`map_estimates_host`."""
+    if "MAP_z_dlas" in results and np.ndim(results["MAP_z_dlas"]) == 1:
+        ind = np.asarray(results["MAP_inds"], dtype=np.float64)
+        return (np.asarray(results["MAP_z_dlas"]), np.asarray(results["MAP_log_nhis"]),
+                np.where(np.isnan(ind), 0, ind - 1).astype(np.int64))
+    return map_estimates_host(results, samples)
 
 
 def _e3(x: float) -> str:

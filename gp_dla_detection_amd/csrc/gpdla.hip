@@ -163,8 +163,31 @@ struct gpdla_batch {
   PixelRow *d_pix = nullptr;
   double *d_Mi = nullptr, *d_lam = nullptr, *d_records = nullptr;
   double *d_sample_ll = nullptr, *d_ll_no = nullptr, *d_summary = nullptr;
-  int64_t pool_rows = 0;
+  int64_t pool_rows = 0, max_pix = 0;
   int32_t k = 0, tiles_w = 0, ntiles = 0;
+  // multi-DLA batch (uploaded with log_priors_lls): result tables, allocated by the first
+  // gpdla_batch_process_multi and kept for the life of the batch
+  int32_t md = 0;  // max_dlas the priors were uploaded for; 0 = single-DLA batch
+  struct MultiBuffers *mb = nullptr;
+};
+
+struct MultiBuffers {
+  double *sll_dla = nullptr, *sll_lls = nullptr, *ll_no = nullptr, *ll_dla = nullptr, *ll_lls = nullptr;
+  double *map_z = nullptr, *map_n = nullptr, *map_i = nullptr, *prof = nullptr;
+  double *lp_lls = nullptr, *lp_dla = nullptr;
+  double *post = nullptr, *scal = nullptr;  // scal: lpost_no, lpost_lls, p_no, p_lls, p_dla [5][nq]; lpost_dla after
+  double *summary = nullptr;                // [nq][GPDLA_SUMMARY_COLS_MULTI(md)]
+  uint32_t *base = nullptr;
+  int32_t *alive = nullptr;
+  int64_t prof_quasars = 0, prof_stride = 0;
+  bool processed = false;
+  ~MultiBuffers() {
+    for (void *p : {(void *)sll_dla, (void *)sll_lls, (void *)ll_no, (void *)ll_dla, (void *)ll_lls,
+                    (void *)map_z, (void *)map_n, (void *)map_i, (void *)prof, (void *)lp_lls,
+                    (void *)lp_dla, (void *)post, (void *)scal, (void *)summary, (void *)base,
+                    (void *)alive})
+      if (p) (void)hipFree(p);
+  }
 };
 
 extern "C" {
@@ -193,6 +216,7 @@ void gpdla_default_config(gpdla_config *cfg) {
   cfg->rng_seed = 0x9E3779B97F4A7C15ull;
   cfg->first_quasar_index = 0;
   cfg->contraction_precision = 0;
+  cfg->multi_profile_bytes = 0;
 }
 
 /* ------------------------------ context ------------------------------ */
@@ -365,6 +389,7 @@ void gpdla_batch_destroy(gpdla_batch *b) {
   dev_free(b->d_sample_ll);
   dev_free(b->d_ll_no);
   dev_free(b->d_summary);
+  delete b->mb;
   delete b;
 }
 
@@ -377,6 +402,9 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
       !sp->pixel_mask || !sp->z_qsos || !sp->log_priors_no_dla || !sp->log_priors_dla)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
   const int64_t nq = sp->num_quasars;
+  const int md = sp->log_priors_lls ? c->cfg.max_dlas : 0;
+  if (sp->log_priors_lls && (md < 1 || md > 4))
+    return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d outside [1, 4]", md);
   for (int64_t q = 0; q < nq; ++q)
     if (sp->offsets[q + 1] < sp->offsets[q])
       return fail(GPDLA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing (quasar %lld)", (long long)q);
@@ -403,8 +431,10 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
     meta[q].lam_off = lam;
     rows += 4 * ((npix + 3) / 4) + 4;
     lam += ((npix + 6 + 1) / 2) * 2 + 2;
+    b->max_pix = std::max(b->max_pix, npix);
   }
   b->pool_rows = rows;
+  b->md = md;
   hipStream_t st = c->stream;
   int rc = GPDLA_OK;
   auto chk = [&](int r) { if (r && !rc) rc = r; };
@@ -415,15 +445,23 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   chk(upload(&b->d_mask, sp->pixel_mask + base, (size_t)b->total_pix, st));
   chk(upload(&b->d_z, sp->z_qsos, (size_t)nq, st));
   chk(upload(&b->d_lp_no, sp->log_priors_no_dla, (size_t)nq, st));
-  chk(upload(&b->d_lp_dla, sp->log_priors_dla, (size_t)nq, st));
+  if (!md) {
+    chk(upload(&b->d_lp_dla, sp->log_priors_dla, (size_t)nq, st));
+  } else {  // multi-DLA batch: [nq][max_dlas] DLA priors + the sub-DLA prior (multi :204-210)
+    b->mb = new MultiBuffers();
+    chk(upload(&b->mb->lp_dla, sp->log_priors_dla, (size_t)nq * md, st));
+    chk(upload(&b->mb->lp_lls, sp->log_priors_lls, (size_t)nq, st));
+  }
   chk(upload(&b->d_meta, meta.data(), (size_t)nq, st));
   chk(dev_alloc(&b->d_pix, (size_t)rows));
   chk(dev_alloc(&b->d_Mi, (size_t)rows * b->k));
   chk(dev_alloc(&b->d_lam, (size_t)lam));
   chk(dev_alloc(&b->d_records, (size_t)(rows / 4) * record_doubles(b->ntiles, 0)));
-  chk(dev_alloc(&b->d_sample_ll, (size_t)nq * b->S));
-  chk(dev_alloc(&b->d_ll_no, (size_t)nq));
-  chk(dev_alloc(&b->d_summary, (size_t)nq * GPDLA_SUMMARY_COLS));
+  if (!md) {
+    chk(dev_alloc(&b->d_sample_ll, (size_t)nq * b->S));
+    chk(dev_alloc(&b->d_ll_no, (size_t)nq));
+    chk(dev_alloc(&b->d_summary, (size_t)nq * GPDLA_SUMMARY_COLS));
+  }
   if (rc) {
     gpdla_batch_destroy(b);
     return rc;
@@ -532,6 +570,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   if (!c || !b || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
   if (b->S != c->S || b->k != c->model.k)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "model/samples changed after the batch was uploaded");
+  if (b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA batch: use gpdla_batch_process_multi");
   HIP_TRY(hipSetDevice(c->device_id));
   hipStream_t st = c->stream;
   int rc = launch_prepare(c, b, false, c->cfg.contraction_precision == 1);
@@ -579,6 +618,9 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   ea.ll_no_dla = b->d_ll_no;
   ea.log_prior_no_dla = b->d_lp_no;
   ea.log_prior_dla = b->d_lp_dla;
+  ea.offset_samples = c->d_offset;
+  ea.nhi_samples = c->d_nhi;
+  ea.log_nhi_samples = c->d_log_nhi;
   ea.S = b->S;
   ea.summary = b->d_summary;
   hipLaunchKernelGGL(k_evidence, dim3((unsigned)b->nq), dim3(256), 0, st, ea);
@@ -588,6 +630,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
 
 int gpdla_batch_summary_device_ptr(gpdla_batch *b, double **table, int64_t *nq) {
   if (!b || !table) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA batch: use gpdla_batch_summary_multi_device_ptr");
   *table = b->d_summary;
   if (nq) *nq = b->nq;
   return GPDLA_OK;
@@ -595,6 +638,7 @@ int gpdla_batch_summary_device_ptr(gpdla_batch *b, double **table, int64_t *nq) 
 
 int gpdla_batch_samples_device_ptr(gpdla_batch *b, double **table, int64_t *nq, int64_t *S) {
   if (!b || !table) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA batch: use gpdla_batch_samples_multi_device_ptr");
   *table = b->d_sample_ll;
   if (nq) *nq = b->nq;
   if (S) *S = b->S;
@@ -603,6 +647,7 @@ int gpdla_batch_samples_device_ptr(gpdla_batch *b, double **table, int64_t *nq, 
 
 int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) {
   if (!c || !b || !r || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched argument");
+  if (b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA batch: use gpdla_batch_download_multi");
   HIP_TRY(hipSetDevice(c->device_id));
   const size_t nq = (size_t)b->nq;
   std::vector<double> summary(nq * GPDLA_SUMMARY_COLS);
@@ -629,6 +674,9 @@ int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) {
     if (r->p_no_dlas) r->p_no_dlas[q] = s[10];
     if (r->p_dlas) r->p_dlas[q] = s[11];
     if (r->status) r->status[q] = meta[q].status;
+    if (r->MAP_inds) r->MAP_inds[q] = s[12];
+    if (r->MAP_z_dlas) r->MAP_z_dlas[q] = s[13];
+    if (r->MAP_log_nhis) r->MAP_log_nhis[q] = s[14];
   }
   return GPDLA_OK;
 }
@@ -763,35 +811,14 @@ int launch_sweep_multi(gpdla_context *c, gpdla_batch *b, const SweepMultiArgs &a
   }
 }
 
-struct MultiBuffers {
-  double *sll_dla = nullptr, *sll_lls = nullptr, *ll_no = nullptr, *ll_dla = nullptr, *ll_lls = nullptr;
-  double *map_z = nullptr, *map_n = nullptr, *map_i = nullptr, *prof = nullptr;
-  double *lp_lls = nullptr, *lp_dla = nullptr;
-  double *post = nullptr, *scal = nullptr;  // scal: lpost_no, lpost_lls, p_no, p_lls, p_dla [5][nq]; lpost_dla after
-  uint32_t *base = nullptr;
-  int32_t *alive = nullptr;
-  ~MultiBuffers() {
-    for (void *p : {(void *)sll_dla, (void *)sll_lls, (void *)ll_no, (void *)ll_dla, (void *)ll_lls,
-                    (void *)map_z, (void *)map_n, (void *)map_i, (void *)prof, (void *)lp_lls,
-                    (void *)lp_dla, (void *)post, (void *)scal, (void *)base, (void *)alive})
-      dev_free(p);
-  }
-};
-
-int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const uint32_t *base_in,
-              gpdla_results_multi *r) {
-  const int64_t nq = b->nq, S = b->S;
-  const int md = c->cfg.max_dlas;
-  if (md < 1 || md > 4) return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d outside [1, 4]", md);
-  if (!c->d_lls_nhi || !c->d_log_nhi)
-    return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs lls_nhi_samples and log_nhi_samples");
-  if (!sp->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
-  hipStream_t st = c->stream;
-  int rc = launch_prepare(c, b, true);
-  if (rc) return rc;
-  MultiBuffers mb;
+// Result tables of a multi-DLA batch, allocated on first use.
+int multi_alloc(gpdla_batch *b) {
+  MultiBuffers &mb = *b->mb;
+  if (mb.sll_dla) return GPDLA_OK;
+  const size_t nqs = (size_t)b->nq, S = (size_t)b->S;
+  const int md = b->md;
+  int rc = GPDLA_OK;
   auto chk = [&](int x) { if (x && !rc) rc = x; };
-  const size_t nqs = (size_t)nq;
   chk(dev_alloc(&mb.sll_dla, nqs * md * S));
   chk(dev_alloc(&mb.sll_lls, nqs * S));
   chk(dev_alloc(&mb.ll_no, nqs));
@@ -802,12 +829,53 @@ int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const u
   chk(dev_alloc(&mb.map_i, nqs * md * md));
   chk(dev_alloc(&mb.base, nqs * (md > 1 ? md - 1 : 1) * S));
   chk(dev_alloc(&mb.alive, nqs));
-  chk(upload(&mb.lp_lls, sp->log_priors_lls, nqs, st));
-  chk(upload(&mb.lp_dla, sp->log_priors_dla, nqs * md, st));
   chk(dev_alloc(&mb.post, nqs * (2 + md)));
   chk(dev_alloc(&mb.scal, nqs * (5 + md)));
+  chk(dev_alloc(&mb.summary, nqs * GPDLA_SUMMARY_COLS_MULTI(md)));
   if (rc) return rc;
-  // NaN pre-fill (multi :110-131); alive = 1; base = 0 (multi :116) or the caller's indices
+  // profile table: rows of `stride` doubles, 2 S rows per quasar, sub-batches sized to the budget
+  const int64_t stride = ((4 * ((b->max_pix + 3) / 4) + 4 + 15) / 16) * 16;
+  const double per_q = 2.0 * (double)S * (double)stride * sizeof(double);
+  const double budget = b->ctx->cfg.multi_profile_bytes > 0 ? (double)b->ctx->cfg.multi_profile_bytes
+                                                            : 16.0 * 1073741824.0;
+  int64_t nq_sub = (int64_t)std::max(1.0, std::floor(budget / per_q));
+  nq_sub = std::min(nq_sub, b->nq);
+  if ((rc = dev_alloc(&mb.prof, (size_t)nq_sub * 2 * S * stride))) return rc;
+  mb.prof_quasars = nq_sub;
+  mb.prof_stride = stride;
+  return GPDLA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *base_in) {
+  if (!c || !b || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
+  if (!b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "not a multi-DLA batch (upload it with log_priors_lls)");
+  if (b->S != c->S || b->k != c->model.k)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "model/samples changed after the batch was uploaded");
+  const int64_t nq = b->nq, S = b->S;
+  const int md = b->md;
+  if (md != c->cfg.max_dlas)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "max_dlas changed after the batch was uploaded (%d -> %d)", md, c->cfg.max_dlas);
+  if (!c->d_lls_nhi || !c->d_log_nhi)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs lls_nhi_samples and log_nhi_samples");
+  const size_t nqs = (size_t)nq;
+  const size_t nbase = nqs * (md > 1 ? md - 1 : 0) * S;
+  if (base_in)  // 0 = never drawn (the sample is NaN); anything above S cannot be an index
+    for (size_t e = 0; e < nbase; ++e)
+      if (base_in[e] > (uint64_t)S)
+        return fail(GPDLA_ERR_INVALID_ARGUMENT, "base_sample_inds[%zu] = %u exceeds num_dla_samples = %lld",
+                    e, base_in[e], (long long)S);
+  HIP_TRY(hipSetDevice(c->device_id));
+  hipStream_t st = c->stream;
+  int rc = multi_alloc(b);
+  if (rc) return rc;
+  MultiBuffers &mb = *b->mb;
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, st));
+  if ((rc = launch_prepare(c, b, true))) return rc;
+  // NaN pre-fill (multi :110-131); alive != 0; base = 0 (multi :116) or the caller's indices
   HIP_TRY(hipMemsetAsync(mb.sll_dla, 0xFF, nqs * md * S * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(mb.sll_lls, 0xFF, nqs * S * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(mb.ll_no, 0xFF, nqs * sizeof(double), st));
@@ -816,28 +884,14 @@ int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const u
   HIP_TRY(hipMemsetAsync(mb.map_z, 0xFF, nqs * md * md * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(mb.map_n, 0xFF, nqs * md * md * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(mb.map_i, 0xFF, nqs * md * md * sizeof(double), st));
-  {
-    std::vector<int32_t> ones(nqs, 1);
-    HIP_TRY(hipMemcpyAsync(mb.alive, ones.data(), nqs * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-  }
-  const size_t nbase = nqs * (md > 1 ? md - 1 : 0) * S;
+  HIP_TRY(hipMemsetAsync(mb.alive, 0x01, nqs * sizeof(int32_t), st));
   if (base_in && nbase)
     HIP_TRY(hipMemcpyAsync(mb.base, base_in, nbase * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   else
     HIP_TRY(hipMemsetAsync(mb.base, 0, (nbase ? nbase : 1) * sizeof(uint32_t), st));
 
-  // profile table: rows of `stride` doubles, 2 S rows per quasar, sub-batches sized to ~16 GiB
-  int64_t max_rows = 0;
-  for (int64_t q = 0; q < nq; ++q) max_rows = std::max(max_rows, sp->offsets[q + 1] - sp->offsets[q]);
-  const int64_t stride = ((4 * ((max_rows + 3) / 4) + 4 + 15) / 16) * 16;
-  const double per_q = 2.0 * (double)S * (double)stride * sizeof(double);
-  int64_t nq_sub = (int64_t)std::max(1.0, std::floor(16.0 * 1073741824.0 / per_q));
-  nq_sub = std::min(nq_sub, nq);
-  chk(dev_alloc(&mb.prof, (size_t)nq_sub * 2 * S * stride));
-  if (rc) return rc;
+  const int64_t nq_sub = mb.prof_quasars, stride = mb.prof_stride;
   const double log_S = std::log((double)S);
-
   for (int64_t q0 = 0; q0 < nq; q0 += nq_sub) {
     const int32_t nsub = (int32_t)std::min(nq_sub, nq - q0);
     ProfilesArgs pa;
@@ -855,9 +909,8 @@ int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const u
     const int64_t waves = (int64_t)nsub * 2 * S;
     hipLaunchKernelGGL(k_profiles, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, pa);
     HIP_TRY(hipGetLastError());
-    for (int mode = 0; mode <= md; ++mode) {  // LLS pass (mode 0) rides with model 1
-      if (mode == 0) continue;
-      for (int pass = (mode == 1 ? 0 : 1); pass < 2; ++pass) {
+    for (int mode = 1; mode <= md; ++mode) {
+      for (int pass = (mode == 1 ? 0 : 1); pass < 2; ++pass) {  // the LLS pass (mode 0) rides with model 1
         SweepMultiArgs sa;
         sa.meta = b->d_meta;
         sa.records = b->d_records;
@@ -920,7 +973,7 @@ int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const u
       }
     }
   }
-  // posteriors over (no DLA, LLS, 1..max_dlas DLAs)
+  // posteriors over (no DLA, LLS, 1..max_dlas DLAs) + the summary row
   MultiPostArgs pp;
   pp.meta = b->d_meta;
   pp.nq = nq;
@@ -938,10 +991,32 @@ int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const u
   pp.p_dla = mb.scal + 4 * nqs;
   pp.lpost_dla = mb.scal + 5 * nqs;
   pp.post = mb.post;
+  pp.map_z = mb.map_z;
+  pp.map_lognhi = mb.map_n;
+  pp.map_ind = mb.map_i;
+  pp.summary = mb.summary;
   hipLaunchKernelGGL(k_multi_posteriors, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, pp);
   HIP_TRY(hipGetLastError());
+  if (c->timing) {
+    HIP_TRY(hipEventRecord(c->ev1, st));
+    c->have_timing = true;
+  }
+  mb.processed = true;
+  return GPDLA_OK;
+}
 
-  // download
+int gpdla_batch_download_multi(gpdla_context *c, gpdla_batch *b, gpdla_results_multi *r) {
+  if (!c || !b || !r || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched argument");
+  if (!b->md || !b->mb || !b->mb->processed)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "no multi-DLA results: call gpdla_batch_process_multi first");
+  HIP_TRY(hipSetDevice(c->device_id));
+  MultiBuffers &mb = *b->mb;
+  hipStream_t st = c->stream;
+  const size_t nqs = (size_t)b->nq, S = (size_t)b->S;
+  const int md = b->md;
+  const size_t nbase = nqs * (md > 1 ? md - 1 : 0) * S;
+  int rc = GPDLA_OK;
+  auto chk = [&](int x) { if (x && !rc) rc = x; };
   std::vector<QuasarMeta> meta(nqs);
   HIP_TRY(hipMemcpyAsync(meta.data(), b->d_meta, nqs * sizeof(QuasarMeta), hipMemcpyDeviceToHost, st));
   auto dl = [&](void *dst, const void *src, size_t bytes) -> int {
@@ -953,13 +1028,13 @@ int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const u
   chk(dl(r->sample_log_likelihoods_lls, mb.sll_lls, nqs * S * 8));
   chk(dl(r->log_likelihoods_dla, mb.ll_dla, nqs * md * 8));
   chk(dl(r->log_likelihoods_lls, mb.ll_lls, nqs * 8));
-  chk(dl(r->log_posteriors_no_dla, pp.lpost_no, nqs * 8));
-  chk(dl(r->log_posteriors_lls, pp.lpost_lls, nqs * 8));
-  chk(dl(r->log_posteriors_dla, pp.lpost_dla, nqs * md * 8));
+  chk(dl(r->log_posteriors_no_dla, mb.scal, nqs * 8));
+  chk(dl(r->log_posteriors_lls, mb.scal + nqs, nqs * 8));
+  chk(dl(r->log_posteriors_dla, mb.scal + 5 * nqs, nqs * md * 8));
   chk(dl(r->model_posteriors, mb.post, nqs * (2 + md) * 8));
-  chk(dl(r->p_no_dlas, pp.p_no, nqs * 8));
-  chk(dl(r->p_lls, pp.p_lls, nqs * 8));
-  chk(dl(r->p_dlas, pp.p_dla, nqs * 8));
+  chk(dl(r->p_no_dlas, mb.scal + 2 * nqs, nqs * 8));
+  chk(dl(r->p_lls, mb.scal + 3 * nqs, nqs * 8));
+  chk(dl(r->p_dlas, mb.scal + 4 * nqs, nqs * 8));
   chk(dl(r->MAP_z_dlas, mb.map_z, nqs * md * md * 8));
   chk(dl(r->MAP_log_nhis, mb.map_n, nqs * md * md * 8));
   chk(dl(r->MAP_inds, mb.map_i, nqs * md * md * 8));
@@ -974,9 +1049,26 @@ int run_multi(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, const u
   return GPDLA_OK;
 }
 
-}  // namespace
+int gpdla_batch_summary_multi_device_ptr(gpdla_batch *b, double **table, int64_t *nq, int32_t *cols) {
+  if (!b || !table) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (!b->md || !b->mb || !b->mb->summary)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "no multi-DLA results: call gpdla_batch_process_multi first");
+  *table = b->mb->summary;
+  if (nq) *nq = b->nq;
+  if (cols) *cols = GPDLA_SUMMARY_COLS_MULTI(b->md);
+  return GPDLA_OK;
+}
 
-extern "C" {
+int gpdla_batch_samples_multi_device_ptr(gpdla_batch *b, double **sll_dla, double **sll_lls,
+                                         uint32_t **base) {
+  if (!b) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (!b->md || !b->mb || !b->mb->sll_dla)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "no multi-DLA results: call gpdla_batch_process_multi first");
+  if (sll_dla) *sll_dla = b->mb->sll_dla;
+  if (sll_lls) *sll_lls = b->mb->sll_lls;
+  if (base) *base = b->mb->base;
+  return GPDLA_OK;
+}
 
 int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
                               const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
@@ -984,6 +1076,7 @@ int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *sam
                               int device_id) {
   if (!model || !samples || !spectra || !results)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (!spectra->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
   gpdla_context *c = nullptr;
   gpdla_batch *b = nullptr;
   int rc = gpdla_context_create(device_id, &c);
@@ -991,21 +1084,17 @@ int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *sam
   gpdla_config cfg;
   gpdla_default_config(&cfg);
   if (config) cfg = *config;
-  // gpdla_batch_upload wants one prior per quasar for the single-DLA table; the multi driver
-  // uploads its own [nq][max_dlas] table, so hand the batch the first column only
-  gpdla_spectra sp1 = *spectra;
-  std::vector<double> first_col;
-  if (spectra->log_priors_dla && spectra->num_quasars > 0 && cfg.max_dlas >= 1) {
-    first_col.resize((size_t)spectra->num_quasars);
-    for (int64_t q = 0; q < spectra->num_quasars; ++q) first_col[q] = spectra->log_priors_dla[q * cfg.max_dlas];
-    sp1.log_priors_dla = first_col.data();
-  }
   if (!(rc = gpdla_context_set_config(c, &cfg)) && !(rc = gpdla_context_set_model(c, model)) &&
-      !(rc = gpdla_context_set_samples(c, samples)) && !(rc = gpdla_batch_upload(c, &sp1, &b)))
-    rc = run_multi(c, b, spectra, base_sample_inds, results);
+      !(rc = gpdla_context_set_samples(c, samples)) && !(rc = gpdla_batch_upload(c, spectra, &b)) &&
+      !(rc = gpdla_batch_process_multi(c, b, base_sample_inds)))
+    rc = gpdla_batch_download_multi(c, b, results);
   gpdla_batch_destroy(b);
   gpdla_context_destroy(c);
   return rc;
+}
+
+void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
 
 /* ------------------------------ training objective (N3) ------------------------------ */

@@ -146,12 +146,21 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   const int64_t i = is_sample ? slot : 0;
   constexpr int nd = ND;  // a.mode == 0 ? 1 : a.mode
   // rows of the profile table this lane multiplies (multi :342-351)
+  // An index outside [1, S] (0 = "never drawn": the rows the reference leaves zero after its early
+  // exit, multi :116, :460-464) is never followed: the sample's likelihood becomes NaN.
   const double *rows[4];
   rows[0] = a.prof + ((ql * 2 + (a.mode == 0 ? 1 : 0)) * a.S + i) * a.stride;
+  int chain_ok = 1;
 #pragma unroll
   for (int j = 1; j < 4; ++j) {
     int64_t kk = i;
-    if (j < nd) kk = (int64_t)a.base_inds[((int64_t)q * (a.max_dlas - 1) + (j - 1)) * a.S + i] - 1;
+    if (j < nd) {
+      kk = (int64_t)a.base_inds[((int64_t)q * (a.max_dlas - 1) + (j - 1)) * a.S + i] - 1;
+      if (kk < 0 || kk >= a.S) {
+        chain_ok = 0;
+        kk = i;
+      }
+    }
     rows[j] = a.prof + ((ql * 2) * a.S + kk) * a.stride;
   }
   const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
@@ -271,10 +280,11 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     const double ll = factor_pass<double, NTW, TS, TW>(acc, xw, xu, p, Eg, lane, role, tile0, a.k, quad_sum,
                                                        logd_sum, m.n_kept, &sigma, &writer);
     const int64_t slot_s = slot0 + sigma;
+    const bool ok_s = __shfl(chain_ok, sigma) != 0;  // lane sigma (jj = 0) holds sample sigma's flag
     if (writer) {
       if (slot_s < a.S) {
         if (a.mode == 0) a.sample_ll_lls[q * a.S + slot_s] = ll - a.log_S;                 // multi :376-378
-        else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ll - a.log_S;  // :359-361
+        else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ok_s ? ll - a.log_S : NAN;  // :359-361
       } else if (slot_s == a.S && a.mode == 1) {
         a.ll_no_dla[q] = ll;                                                                // multi :296-298
       }
@@ -377,8 +387,13 @@ __global__ __launch_bounds__(256) void k_multi_evidence(MultiEvidenceArgs a) {
     for (int64_t i = tid; i < a.S; i += 256) {
       double zs[4];
       zs[0] = m.min_z_dla + zr * a.offset_samples[i];
-      for (int j = 1; j < nd; ++j) zs[j] = m.min_z_dla + zr * a.offset_samples[base[(int64_t)(j - 1) * a.S + i] - 1];
       bool close = false;
+      for (int j = 1; j < nd; ++j) {
+        const int64_t bj = (int64_t)base[(int64_t)(j - 1) * a.S + i] - 1;
+        const bool ok = bj >= 0 && bj < a.S;  // undrawn / out-of-range index: the sample is NaN
+        close |= !ok;
+        zs[j] = m.min_z_dla + zr * a.offset_samples[ok ? bj : i];
+      }
       for (int x = 0; x < nd; ++x)
         for (int y = x + 1; y < nd; ++y) close |= fabs(zs[x] - zs[y]) < a.min_z_separation;
       if (close) col[i] = NAN;
@@ -395,6 +410,7 @@ __global__ __launch_bounds__(256) void k_multi_evidence(MultiEvidenceArgs a) {
     for (int j = 0; j < nd; ++j) {
       const int64_t idx = j == 0 ? arg : (int64_t)base[(int64_t)(j - 1) * a.S + arg] - 1;
       const int64_t at = ((int64_t)q * md + (nd - 1)) * md + j;
+      if (idx < 0 || idx >= a.S) continue;  // undrawn index (all-NaN column): slot stays NaN
       a.map_ind[at] = (double)(idx + 1);
       a.map_z[at] = m.min_z_dla + zr * a.offset_samples[idx];
       a.map_lognhi[at] = a.log_nhi_samples[idx];
@@ -415,7 +431,7 @@ __global__ __launch_bounds__(256) void k_multi_evidence(MultiEvidenceArgs a) {
 // keyed by (seed, global quasar index) with counter (draw j, model nd), inverse-CDF sampling on the
 // prefix sums of W taken in sample order.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t *out) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
@@ -505,6 +521,8 @@ struct MultiPostArgs {
   const double *lp_no, *lp_lls, *lp_dla;   // log priors: [nq], [nq], [nq][max_dlas]
   const double *ll_no, *ll_lls, *ll_dla;
   double *lpost_no, *lpost_lls, *lpost_dla, *post, *p_no, *p_lls, *p_dla;
+  const double *map_z, *map_lognhi, *map_ind;   // [nq][max_dlas][max_dlas]
+  double *summary;   // [nq][14 + 4 md + 3 md^2], layout: GPDLA_SUMMARY_COLS_MULTI in gpdla.h
 };
 
 __global__ void k_multi_posteriors(MultiPostArgs a) {
@@ -535,6 +553,28 @@ __global__ void k_multi_posteriors(MultiPostArgs a) {
   a.p_no[q] = a.post[q * nm];
   a.p_lls[q] = a.post[q * nm + 1];
   a.p_dla[q] = 1 - a.p_no[q] - a.p_lls[q];  // :493-495
+  // the row a multi-GPU run gathers: every saved variable of multi :498-510 that is not per-sample
+  const QuasarMeta m = a.meta[q];
+  double *o = a.summary + q * (14 + 4 * md + 3 * md * md);
+  *o++ = m.min_z_dla;
+  *o++ = m.max_z_dla;
+  *o++ = a.lp_no[q];
+  *o++ = a.lp_lls[q];
+  for (int j = 0; j < md; ++j) *o++ = a.lp_dla[q * md + j];
+  *o++ = a.ll_no[q];
+  *o++ = a.ll_lls[q];
+  for (int j = 0; j < md; ++j) *o++ = a.ll_dla[q * md + j];
+  *o++ = lp[0];
+  *o++ = lp[1];
+  for (int j = 0; j < md; ++j) *o++ = lp[2 + j];
+  for (int j = 0; j < nm; ++j) *o++ = a.post[q * nm + j];
+  *o++ = a.p_no[q];
+  *o++ = a.p_lls[q];
+  *o++ = a.p_dla[q];
+  for (int j = 0; j < md * md; ++j) *o++ = a.map_z[q * md * md + j];
+  for (int j = 0; j < md * md; ++j) *o++ = a.map_lognhi[q * md * md + j];
+  for (int j = 0; j < md * md; ++j) *o++ = a.map_ind[q * md * md + j];
+  *o++ = m.status == 1 ? 1.0 : NAN;  // all_exceptions, multi :139, :232
 }
 
 }  // namespace gpdla

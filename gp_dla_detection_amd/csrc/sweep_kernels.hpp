@@ -1229,30 +1229,55 @@ struct EvidenceArgs {
   const double *sample_ll;   // [nq][S]
   const double *ll_no_dla;   // [nq]
   const double *log_prior_no_dla, *log_prior_dla;
+  const double *offset_samples, *nhi_samples, *log_nhi_samples;  // log_nhi_samples may be null
   int64_t S;
-  double *summary;           // [nq][12]
+  double *summary;           // [nq][kSummaryCols]
 };
+constexpr int kSummaryCols = 15;
 
 __global__ __launch_bounds__(256) void k_evidence(EvidenceArgs a) {
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ double sh[4];
+  __shared__ long long sh_arg[4];
   const QuasarMeta m = a.meta[q];
-  double *out = a.summary + (int64_t)q * 12;
+  double *out = a.summary + (int64_t)q * kSummaryCols;
   if (m.status != 0) {
-    if (tid < 12) out[tid] = NAN;
+    if (tid < kSummaryCols) out[tid] = NAN;
     if (tid == 2) out[2] = a.log_prior_no_dla[q];
     if (tid == 3) out[3] = a.log_prior_dla[q];
     return;
   }
   const double *ll = a.sample_ll + (int64_t)q * a.S;
   double mx = -INFINITY;
-  bool has_nan = false;
+  long long arg = a.S;  // first index attaining the nanmax (generate_ascii_catalog.m:73)
   for (int64_t i = tid; i < a.S; i += 256) {
     const double v = ll[i];
-    has_nan |= isnan(v);
-    mx = fmax(mx, v);  // fmax skips NaN like MATLAB's max (:203)
+    if (v > mx || (v == mx && i < arg)) {  // NaN compares false: skipped like MATLAB's max (:203)
+      mx = v;
+      arg = i;
+    }
   }
-  mx = block_reduce_minmax(mx, false, sh);
+  for (int o = 32; o > 0; o >>= 1) {
+    const double om = __shfl_xor(mx, o);
+    const long long oa = __shfl_xor(arg, o);
+    if (om > mx || (om == mx && oa < arg)) {
+      mx = om;
+      arg = oa;
+    }
+  }
+  if (lane == 0) {
+    sh[wave] = mx;
+    sh_arg[wave] = arg;
+  }
+  __syncthreads();
+  mx = sh[0];
+  arg = sh_arg[0];
+  for (int w = 1; w < 4; ++w)
+    if (sh[w] > mx || (sh[w] == mx && sh_arg[w] < arg)) {
+      mx = sh[w];
+      arg = sh_arg[w];
+    }
+  if (arg >= a.S) arg = 0;  // all NaN (or all -inf): MATLAB's nanmax returns index 1
   double sum = 0.0;
   for (int64_t i = tid; i < a.S; i += 256) sum += exp(ll[i] - mx);  // :205-207 (NaN propagates)
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -1282,6 +1307,10 @@ __global__ __launch_bounds__(256) void k_evidence(EvidenceArgs a) {
     out[9] = p1;
     out[10] = p0;        // p_no_dlas, :232
     out[11] = 1 - p0;    // p_dlas,    :233
+    // generate_ascii_catalog.m:73-80
+    out[12] = (double)(arg + 1);
+    out[13] = m.min_z_dla + (m.max_z_dla - m.min_z_dla) * a.offset_samples[arg];
+    out[14] = a.log_nhi_samples ? a.log_nhi_samples[arg] : log10(a.nhi_samples[arg]);
   }
 }
 

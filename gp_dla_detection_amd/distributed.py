@@ -2,21 +2,29 @@
 
 The reference's only multi-node mechanism is "run process_qsos on disjoint ``test_ind`` slices as
 separate batch jobs, then concatenate the .mat chunks along the quasar axis"
-(CDDF_analysis/sbatch_reunion.py:13-63).  Quasars are independent (serial outer loop with no
-carried state, process_qsos.m:88), so the MI355X-native equivalent is: one process per GPU, each
-sweeping a contiguous block of quasars balanced by pixel count, no communication during compute,
-and one ``all_gather`` of the small per-quasar summary row (12 fp64 = 96 B; 15.6 MB for DR12Q's
-162 861 quasars) over RCCL/xGMI at the end.  ``sample_log_likelihoods_dla`` (80 KB per quasar) is
-NOT gathered: each rank keeps its shard, as the reference keeps per-job chunks.
+(CDDF_analysis/sbatch_reunion.py:13-63; every key is concatenated, the multi-DLA ones included,
+:29-55).  Quasars are independent (serial outer loop with no carried state, process_qsos.m:88),
+so the MI355X-native equivalent is: one process per GPU, each sweeping a contiguous block of
+quasars balanced by pixel count, no communication during compute, and one ``all_gather`` of the
+small per-quasar summary row over RCCL/xGMI at the end:
+
+* single-DLA: 15 fp64 = 120 B per quasar (19.5 MB for DR12Q's 162 861 quasars);
+* multi-DLA: ``14 + 4 max_dlas + 3 max_dlas^2`` fp64 = 78 for max_dlas = 4 (624 B; 102 MB).
+
+The per-sample tables (``sample_log_likelihoods_dla``: 80 KB per quasar and model,
+``base_sample_inds``) are NOT gathered: each rank keeps its shard, as the reference keeps per-job
+chunk files.  A rank only needs its own block of spectra: pass a loader instead of the full list.
 """
 from __future__ import annotations
+
+from dataclasses import replace
 
 import numpy as np
 
 SUMMARY_COLUMNS = ("min_z_dlas", "max_z_dlas", "log_priors_no_dla", "log_priors_dla",
                    "log_likelihoods_no_dla", "log_likelihoods_dla", "log_posteriors_no_dla",
                    "log_posteriors_dla", "model_posteriors_no_dla", "model_posteriors_dla",
-                   "p_no_dlas", "p_dlas")
+                   "p_no_dlas", "p_dlas", "MAP_inds", "MAP_z_dlas", "MAP_log_nhis")
 
 
 def shard_bounds(pixel_counts, world_size: int):
@@ -39,15 +47,18 @@ def shard_bounds(pixel_counts, world_size: int):
 
 
 def gather_summaries(local_table, counts=None, group=None):
-    """All-gather the per-quasar summary rows of every rank into the full [nq_total, 12] table, in
-    rank (= quasar) order.  ``local_table``: torch tensor [nq_local, 12] on this rank's device
-    (``Batch.summary_tensor()``); works on CPU tensors with gloo as well.  ``counts``: rows per
-    rank if already known (skips the size exchange)."""
+    """All-gather the per-quasar summary rows of every rank into the full [nq_total, ncol] table,
+    in rank (= quasar) order.  ``local_table``: torch tensor [nq_local, ncol] on this rank's device
+    (``Batch.summary_tensor()``); a rank whose block is empty passes a [0, ncol] tensor.  With the
+    gloo backend (CPU rehearsal of the multi-process path) device tensors are staged through host
+    memory.  ``counts``: rows per rank if already known (skips the size exchange)."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_table
+    if dist.get_backend(group) == "gloo" and local_table.is_cuda:
+        local_table = local_table.cpu()
     world = dist.get_world_size(group)
     ncol = local_table.shape[1]
     if counts is None:
@@ -57,7 +68,8 @@ def gather_summaries(local_table, counts=None, group=None):
         counts = [int(s.item()) for s in sizes]
     if len(set(counts)) == 1:
         out = torch.empty((world * counts[0], ncol), dtype=local_table.dtype, device=local_table.device)
-        dist.all_gather_into_tensor(out, local_table.contiguous(), group=group)
+        if counts[0]:
+            dist.all_gather_into_tensor(out, local_table.contiguous(), group=group)
         return out
     width = max(counts)
     padded = torch.zeros((width, ncol), dtype=local_table.dtype, device=local_table.device)
@@ -68,8 +80,8 @@ def gather_summaries(local_table, counts=None, group=None):
 
 
 def summary_to_fields(table) -> dict:
-    """Split a gathered [nq, 12] table into the reference's output variables
-    (process_qsos.m:236-244)."""
+    """Split a gathered [nq, 15] table into the reference's output variables
+    (process_qsos.m:236-244) plus the MAP columns of generate_ascii_catalog.m:73-80."""
     t = table.detach().cpu().numpy() if hasattr(table, "detach") else np.asarray(table)
     out = {name: t[:, i].copy() for i, name in enumerate(SUMMARY_COLUMNS)}
     out["model_posteriors"] = np.stack([out.pop("model_posteriors_no_dla"),
@@ -77,36 +89,165 @@ def summary_to_fields(table) -> dict:
     return out
 
 
-def process_qsos_sharded(model, samples, spectra, log_priors, params=None, device=None):
-    """process_qsos over every quasar of ``spectra`` with the work split across the ranks of the
-    default process group.  Every rank passes the same full list; returns (gathered summary
-    fields, this rank's (lo, hi) block, this rank's sample_log_likelihoods_dla)."""
-    import torch
-    import torch.distributed as dist
+def summary_to_fields_multi(table, max_dlas: int) -> dict:
+    """Split a gathered multi-DLA table (layout: GPDLA_SUMMARY_COLS_MULTI in include/gpdla.h) into
+    the variables process_qsos_multiple_dlas_meanflux.m:498-510 saves (per-sample arrays aside)."""
+    t = table.detach().cpu().numpy() if hasattr(table, "detach") else np.asarray(table)
+    md, nq = int(max_dlas), t.shape[0]
+    if t.shape[1] != 14 + 4 * md + 3 * md * md:
+        raise ValueError(f"table has {t.shape[1]} columns, max_dlas = {md} needs {14 + 4 * md + 3 * md * md}")
+    pos = [0]
 
+    def take(n, shape=None):
+        a = t[:, pos[0]: pos[0] + n].copy()
+        pos[0] += n
+        return a[:, 0] if shape is None else a.reshape((nq,) + shape)
+
+    out = {}
+    out["min_z_dlas"], out["max_z_dlas"] = take(1), take(1)
+    out["log_priors_no_dla"], out["log_priors_lls"] = take(1), take(1)
+    out["log_priors_dla"] = take(md, (md,))
+    out["log_likelihoods_no_dla"], out["log_likelihoods_lls"] = take(1), take(1)
+    out["log_likelihoods_dla"] = take(md, (md,))
+    out["log_posteriors_no_dla"], out["log_posteriors_lls"] = take(1), take(1)
+    out["log_posteriors_dla"] = take(md, (md,))
+    out["model_posteriors"] = take(2 + md, (2 + md,))
+    out["p_no_dlas"], out["p_lls"], out["p_dlas"] = take(1), take(1), take(1)
+    for name in ("MAP_z_dlas", "MAP_log_nhis", "MAP_inds"):
+        out[name] = take(md * md, (md, md))
+    out["all_exceptions"] = take(1)
+    return out
+
+
+def _world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def _block(spectra, pixel_counts, lo, hi):
+    """This rank's spectra: a slice of the full list, or whatever the loader returns for [lo, hi)."""
+    if callable(spectra):
+        block = list(spectra(lo, hi))
+        if len(block) != hi - lo:
+            raise ValueError(f"loader returned {len(block)} spectra for block [{lo}, {hi})")
+        return block
+    return list(spectra[lo:hi])
+
+
+def _pixel_counts(spectra, pixel_counts):
+    if pixel_counts is not None:
+        return np.asarray(pixel_counts)
+    if callable(spectra):
+        raise ValueError("a spectra loader needs pixel_counts (one entry per quasar)")
+    return np.array([np.asarray(s["wavelengths"]).size for s in spectra])
+
+
+def run_sharded(bounds, rank, ncol, sweep_block, group=None):
+    """The sharding skeleton shared by both drivers: ``sweep_block(lo, hi)`` returns this rank's
+    (summary tensor [hi-lo, ncol], local per-sample results); a rank with an empty block skips
+    the sweep and contributes a [0, ncol] table, so the collective is reached by every rank.
+    Returns (gathered table, (lo, hi), local results or None)."""
+    import torch
+    lo, hi = bounds[rank]
+    if hi > lo:
+        table, local = sweep_block(lo, hi)
+    else:
+        table, local = torch.empty((0, ncol), dtype=torch.float64), None
+    counts = [b[1] - b[0] for b in bounds]
+    if len(bounds) > 1 and hi == lo:  # put the empty table where the other ranks' tables live
+        import torch.distributed as dist
+        if dist.get_backend(group) != "gloo" and torch.cuda.is_available():
+            table = table.to(torch.device("cuda", torch.cuda.current_device()))
+    return gather_summaries(table, counts, group), (lo, hi), local
+
+
+def process_qsos_sharded(model, samples, spectra, log_priors, params=None, device=None,
+                         pixel_counts=None):
+    """process_qsos over every quasar with the work split across the ranks of the default process
+    group.  ``spectra``: the full list (every rank passes the same one), or a loader
+    ``f(lo, hi) -> list`` together with ``pixel_counts`` so that a rank reads only its block.
+    ``log_priors = (no_dla, dla)`` for ALL quasars.  Returns (gathered summary fields for all
+    quasars, this rank's (lo, hi) block, this rank's sample_log_likelihoods_dla [hi-lo, S] or
+    None for an empty block)."""
+    import torch
+
+    from . import _lib
     from .api import Context
 
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    world, rank = _world()
     if device is None:
         device = torch.cuda.current_device()
-    sizes = [np.asarray(s["wavelengths"]).size for s in spectra]
-    bounds = shard_bounds(sizes, world)
-    lo, hi = bounds[rank]
-    ctx = Context(device, params)
-    try:
-        ctx.set_model(model)
-        ctx.set_samples(samples)
-        batch = ctx.upload(spectra[lo:hi], np.asarray(log_priors[0])[lo:hi],
-                           np.asarray(log_priors[1])[lo:hi])
+    bounds = shard_bounds(_pixel_counts(spectra, pixel_counts), world)
+    lp_no, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
+
+    def sweep_block(lo, hi):
+        ctx = Context(device, params)
         try:
-            batch.process()
-            ctx.synchronize()
-            table = gather_summaries(batch.summary_tensor(), [b[1] - b[0] for b in bounds])
-            fields = summary_to_fields(table)
-            local = batch.download()["sample_log_likelihoods_dla"]
+            ctx.set_model(model)
+            ctx.set_samples(samples)
+            batch = ctx.upload(_block(spectra, pixel_counts, lo, hi), lp_no[lo:hi], lp_dla[lo:hi])
+            try:
+                batch.process()
+                ctx.synchronize()
+                table = batch.summary_tensor().clone()
+                local = batch.download()["sample_log_likelihoods_dla"]
+            finally:
+                batch.close()
         finally:
-            batch.close()
-    finally:
-        ctx.close()
-    return fields, (lo, hi), local
+            ctx.close()
+        return table, local
+
+    table, block, local = run_sharded(bounds, rank, _lib.SUMMARY_COLS, sweep_block)
+    return summary_to_fields(table), block, local
+
+
+def process_qsos_multiple_dlas_meanflux_sharded(model, samples, spectra, log_priors, params=None,
+                                                device=None, pixel_counts=None,
+                                                base_sample_inds=None):
+    """The multi-DLA driver split across ranks.  ``log_priors = (no_dla [nq], lls [nq], dla [nq,
+    max_dlas])`` for ALL quasars.  Each rank's batch is told the global index of its first quasar
+    (``first_quasar_index``), which keys the Philox stream of the weighted resampling (multi
+    :467-472), so the indices drawn -- and with them every result -- equal those of an unsharded
+    run.  ``base_sample_inds`` (optional, [nq, max_dlas-1, S] for ALL quasars) replays supplied
+    indices instead.  Returns (gathered summary fields, (lo, hi), this rank's per-sample results:
+    dict with sample_log_likelihoods_dla [hi-lo, max_dlas, S], sample_log_likelihoods_lls,
+    base_sample_inds; None for an empty block)."""
+    import torch
+
+    from . import _lib
+    from .api import Context
+    from .parameters import MultiParameters
+
+    p = params or MultiParameters()
+    world, rank = _world()
+    if device is None:
+        device = torch.cuda.current_device()
+    bounds = shard_bounds(_pixel_counts(spectra, pixel_counts), world)
+    lp_no, lp_lls, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
+    lp_dla = lp_dla.reshape(lp_no.size, p.max_dlas)
+
+    def sweep_block(lo, hi):
+        ctx = Context(device, replace(p, first_quasar_index=p.first_quasar_index + lo))
+        try:
+            ctx.set_model(model)
+            ctx.set_samples(samples)
+            batch = ctx.upload(_block(spectra, pixel_counts, lo, hi), lp_no[lo:hi], lp_dla[lo:hi],
+                               lp_lls[lo:hi])
+            try:
+                batch.process_multi(None if base_sample_inds is None else
+                                    np.asarray(base_sample_inds)[lo:hi])
+                ctx.synchronize()
+                table = batch.summary_tensor().clone()
+                res = batch.download_multi()
+                local = {key: res[key] for key in ("sample_log_likelihoods_dla",
+                                                   "sample_log_likelihoods_lls", "base_sample_inds")}
+            finally:
+                batch.close()
+        finally:
+            ctx.close()
+        return table, local
+
+    table, block, local = run_sharded(bounds, rank, _lib.summary_cols_multi(p.max_dlas), sweep_block)
+    return summary_to_fields_multi(table, p.max_dlas), block, local

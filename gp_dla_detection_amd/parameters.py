@@ -55,3 +55,4 @@ class MultiParameters(Parameters):
     num_forest_lines: int = 31                 # set_parameters_multi.m:75
     rng_seed: int = 0x9E3779B97F4A7C15         # GPU resampling stream (the reference: rng('default'))
     first_quasar_index: int = 0                # global index of this batch's first quasar (sharding)
+    multi_profile_bytes: int = 0               # HBM budget of the Voigt profile table; 0 = 16 GiB

@@ -38,7 +38,7 @@ typedef enum {
 } gpdla_status;
 
 #define GPDLA_MAX_K 40
-#define GPDLA_ABI_VERSION 1
+#define GPDLA_ABI_VERSION 2
 
 int gpdla_abi_version(void);
 /* Human-readable text of the most recent error on this thread (never NULL). */
@@ -55,7 +55,9 @@ int gpdla_voigt(const double *lambdas, int64_t n_padded, double z, double N, int
                 double *profile_out, int device_id);
 
 /* log_mvnpdf_low_rank.m:5-34.  y, mu, d: n;  M: n x k column-major (ld = n).  A non-PD
- * B = I + M' D^-1 M returns GPDLA_ERR_NOT_POSITIVE_DEFINITE and *log_p = NaN (MATLAB: chol throws). */
+ * B = I + M' D^-1 M returns GPDLA_ERR_NOT_POSITIVE_DEFINITE and *log_p = NaN (MATLAB: chol throws).
+ * The MATLAB function takes any k; this stand-alone surface accepts k <= 256 (the batch sweep,
+ * whose accumulators live in registers, is the one limited to GPDLA_MAX_K). */
 int gpdla_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M, const double *d,
                               int64_t n, int k, double *log_p, int device_id);
 
@@ -122,6 +124,9 @@ typedef struct {
    * variant -- contraction on the fp32 matrix cores, everything else (Voigt profile, weights,
    * quadratic form, log-determinant, Cholesky) in fp64.  Not parity-grade; single-DLA sweep only. */
   int32_t contraction_precision;
+  /* multi-DLA driver: bytes of HBM the per-quasar Voigt profile table (2 S rows per quasar) may take
+   * at a time; quasars are swept in sub-batches that fit.  0 = default (16 GiB). */
+  int64_t multi_profile_bytes;
 } gpdla_config;
 
 /* Fills a gpdla_config with the reference's defaults (set_parameters.m / set_parameters_multi.m). */
@@ -144,6 +149,13 @@ typedef struct {
   double *p_no_dlas;                  /* [nq] */
   double *p_dlas;                     /* [nq] */
   int32_t *status;                    /* [nq] 0 ok, 1 = empty spectrum (multi: all_exceptions, :232) */
+  /* generate_ascii_catalog.m:73-80, found by the evidence kernel while it walks the table anyway:
+   * [~, map_ind] = nanmax(sample_log_likelihoods_dla(i, :)) (1-based, first index on ties; 1 for an
+   * all-NaN row, as MATLAB returns), map_z_dla = min_z + (max_z - min_z) * offset_samples(map_ind),
+   * log_nhi_samples(map_ind) (log10 of nhi_samples(map_ind) when log_nhi_samples was not given). */
+  double *MAP_inds;                   /* [nq] */
+  double *MAP_z_dlas;                 /* [nq] */
+  double *MAP_log_nhis;               /* [nq] */
 } gpdla_results;
 
 /* One-shot: host buffers in, host buffers out (uploads, sweeps, downloads). */
@@ -168,7 +180,10 @@ int gpdla_context_set_samples(gpdla_context *ctx, const gpdla_samples *samples);
 int gpdla_context_set_config(gpdla_context *ctx, const gpdla_config *config);
 int gpdla_context_synchronize(gpdla_context *ctx);
 
-/* Copies a CSR batch of spectra to HBM and allocates its result table there. */
+/* Copies a CSR batch of spectra to HBM and allocates its result table there.  With
+ * spectra->log_priors_lls != NULL the batch is a multi-DLA batch: log_priors_dla is then
+ * [nq][max_dlas] (max_dlas of the context's config at this call) and the batch is processed with
+ * gpdla_batch_process_multi. */
 int gpdla_batch_upload(gpdla_context *ctx, const gpdla_spectra *spectra, gpdla_batch **batch);
 void gpdla_batch_destroy(gpdla_batch *batch);
 
@@ -182,9 +197,10 @@ int gpdla_batch_download(gpdla_context *ctx, gpdla_batch *batch, gpdla_results *
 
 /* Device pointer to the per-quasar summary table of the batch, [nq][GPDLA_SUMMARY_COLS] doubles:
  * min_z_dla, max_z_dla, log_prior_no_dla, log_prior_dla, log_likelihood_no_dla, log_likelihood_dla,
- * log_posterior_no_dla, log_posterior_dla, model_posterior[0], model_posterior[1], p_no_dla, p_dla.
+ * log_posterior_no_dla, log_posterior_dla, model_posterior[0], model_posterior[1], p_no_dla, p_dla,
+ * MAP_ind (1-based), MAP_z_dla, MAP_log_nhi (generate_ascii_catalog.m:73-80).
  * This is the row a multi-GPU run all-gathers. */
-#define GPDLA_SUMMARY_COLS 12
+#define GPDLA_SUMMARY_COLS 15
 int gpdla_batch_summary_device_ptr(gpdla_batch *batch, double **table, int64_t *num_quasars);
 /* Device pointer to sample_log_likelihoods_dla [nq][S] of the batch. */
 int gpdla_batch_samples_device_ptr(gpdla_batch *batch, double **table, int64_t *num_quasars,
@@ -227,6 +243,32 @@ int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *sam
                               const gpdla_config *config, gpdla_results_multi *results,
                               int device_id);
 
+/* Resident form of the same driver: the batch was uploaded with log_priors_lls (see
+ * gpdla_batch_upload).  base_sample_inds: HOST pointer [nq][max_dlas-1][S] (1-based; an entry 0
+ * means "never drawn", as in the rows the reference leaves zero after its early exit, :116,
+ * :460-464 -- a sample that would consume it gets NaN; entries > S are rejected) or NULL to draw
+ * on the GPU.  Asynchronous on the context's stream apart from that one H2D copy; every result
+ * stays in HBM until gpdla_batch_download_multi. */
+int gpdla_batch_process_multi(gpdla_context *ctx, gpdla_batch *batch,
+                              const uint32_t *base_sample_inds);
+int gpdla_batch_download_multi(gpdla_context *ctx, gpdla_batch *batch, gpdla_results_multi *results);
+
+/* Per-quasar summary row of a multi-DLA batch -- every saved variable of multi :498-510 that is not
+ * a per-sample array; the row a multi-GPU run all-gathers.  Layout, md =
+ * max_dlas: min_z_dla, max_z_dla | log_prior_no_dla, log_prior_lls, log_prior_dla[md] |
+ * log_likelihood_no_dla, log_likelihood_lls, log_likelihood_dla[md] | log_posterior_no_dla,
+ * log_posterior_lls, log_posterior_dla[md] | model_posteriors[2+md] | p_no_dla, p_lls, p_dla |
+ * MAP_z_dlas[md][md], MAP_log_nhis[md][md], MAP_inds[md][md] ([model][slot]) | all_exceptions
+ * (1 or NaN, :139, :232).  78 columns for max_dlas = 4. */
+#define GPDLA_SUMMARY_COLS_MULTI(md) (14 + 4 * (md) + 3 * (md) * (md))
+int gpdla_batch_summary_multi_device_ptr(gpdla_batch *batch, double **table, int64_t *num_quasars,
+                                         int32_t *num_cols);
+/* Device pointers to the per-sample tables of a multi-DLA batch (valid after the first
+ * gpdla_batch_process_multi): sample_log_likelihoods_dla [nq][max_dlas][S],
+ * sample_log_likelihoods_lls [nq][S], base_sample_inds [nq][max_dlas-1][S].  Any may be NULL. */
+int gpdla_batch_samples_multi_device_ptr(gpdla_batch *batch, double **sample_ll_dla,
+                                         double **sample_ll_lls, uint32_t **base_sample_inds);
+
 /* ---------------------------------------------------------------------------------------------
  * Training objective: objective.m:12-75 over spectrum_loss.m:14-76.
  * The training set stays resident in HBM; each call evaluates f(x) and g(x) = df/dx for
@@ -250,6 +292,11 @@ void gpdla_training_destroy(gpdla_training *t);
  * (may be NULL).  Needs no GPU.
  * ------------------------------------------------------------------------------------------- */
 int gpdla_debug_near_poly(int line, double x, double *value_out, double *y_out);
+
+/* The counter-based generator behind the multi-DLA resampling (Philox4x32-10 of Salmon et al.,
+ * SC'11), evaluated on the HOST by the same function the kernel compiles: out = philox(ctr, key).
+ * For known-answer tests against the Random123 vectors.  Needs no GPU. */
+void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Multi-process GPU tests (test_gpu_sharded.py) fork their ranks from a fork server.  It is started
+# here, before any test can touch the GPU, so that no process holding a HIP context ever forks or
+# execs (on the GPU pool that is forbidden); the ranks are clean children of a clean server.
+import multiprocessing as _mp  # noqa: E402
+import multiprocessing.forkserver as _forkserver  # noqa: E402
+
+_mp.set_forkserver_preload(["numpy"])
+_forkserver.ensure_running()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -1,0 +1,68 @@
+"""Worker of the multi-process rehearsal in test_gpu_sharded.py: one rank of a world of N processes
+that all use cuda:0 (a one-GPU box), talking over gloo.  The code under test is exactly what an
+8-GPU run executes -- gp_dla_detection_amd.distributed.process_qsos_sharded and its multi-DLA
+sibling -- only the backend (gloo for RCCL) and the device mapping (every rank on cuda:0) differ.
+
+The processes are forked from a fork server that conftest.py starts BEFORE anything touches the
+GPU, so no process that holds a HIP context ever forks or execs.
+"""
+import os
+
+import numpy as np
+
+
+def build_case(kind):
+    """Seeded inputs, identical in every process."""
+    import gp_dla_detection_amd as gp
+    from gp_dla_detection_amd import synthetic
+    from gp_dla_detection_amd.parameters import MultiParameters
+    model = synthetic.make_model(20)
+    sizes = [310, 640, 222, 801, 415, 333, 560]
+    spectra = [synthetic.make_spectrum(830 + i, n, model, mask_fraction=0.04 if i % 2 else 0.0)
+               for i, n in enumerate(sizes)]
+    cat = synthetic.make_prior_catalog()
+    z = np.array([s["z_qso"] for s in spectra])
+    if kind == "single":
+        samples = synthetic.make_samples(700)
+        return model, samples, spectra, gp.dla_existence_prior(cat["z_qsos"], cat["dla_ind"], z), None
+    p = MultiParameters(max_dlas=3)
+    samples = synthetic.make_samples(384)
+    lp = gp.dla_existence_prior_multi(cat["z_qsos"], cat["dla_ind"], z, 0.31, 0.69, p)
+    return model, samples, spectra, lp, p
+
+
+def run_rank(rank, world, port, kind, out_dir, num_quasars):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from gp_dla_detection_amd import distributed
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, samples, spectra, lp, p = build_case(kind)
+        spectra = spectra[:num_quasars]
+        lp = tuple(np.asarray(x)[:num_quasars] for x in lp)
+        counts = [np.asarray(s["wavelengths"]).size for s in spectra]
+        loaded = []
+
+        def loader(lo, hi):  # a rank reads ONLY its block
+            loaded.append((lo, hi))
+            return spectra[lo:hi]
+
+        if kind == "single":
+            fields, block, local = distributed.process_qsos_sharded(
+                model, samples, loader, lp, device=0, pixel_counts=counts)
+            local = {} if local is None else {"sample_log_likelihoods_dla": local}
+        else:
+            fields, block, local = distributed.process_qsos_multiple_dlas_meanflux_sharded(
+                model, samples, loader, lp, params=p, device=0, pixel_counts=counts)
+            local = local or {}
+        assert loaded == ([block] if block[1] > block[0] else [])
+        np.savez(os.path.join(out_dir, f"{kind}_w{world}_r{rank}.npz"), block=np.array(block),
+                 **{"f_" + k: v for k, v in fields.items()}, **{"l_" + k: v for k, v in local.items()})
+    finally:
+        if world > 1:
+            dist.destroy_process_group()

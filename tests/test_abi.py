@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_typed(lib):
     for n in names:
         assert hasattr(lib, n), f"libgpdla.so does not export {n}"
         assert n in typed, f"{n} has no ctypes signature in _lib.SYMBOLS"
-    assert lib.gpdla_abi_version() == 1
+    assert lib.gpdla_abi_version() == 2
 
 
 def test_struct_layouts_match_header(lib):
@@ -42,6 +42,110 @@ def test_struct_layouts_match_header(lib):
     assert cfg.max_dlas == 4 and cfg.num_forest_lines == 31
     assert abs(cfg.min_z_separation - 3000 * 1000 / 299792458) < 1e-18
     assert (cfg.prev_tau_0, cfg.prev_beta) == (0.0023, 3.65)
+    assert cfg.rng_seed == 0x9E3779B97F4A7C15 and cfg.first_quasar_index == 0
+    assert cfg.contraction_precision == 0 and cfg.multi_profile_bytes == 0
+
+
+C_CONSUMER = r"""
+/* A C99 consumer of include/gpdla.h: prints the layout the COMPILER gives every struct of the
+ * boundary, calls through the declared prototypes, and checks the default config. */
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include "gpdla.h"
+#define OFF(T, f) printf(#T "." #f " %zu\n", offsetof(T, f))
+int main(void) {
+  printf("sizeof gpdla_model %zu\n", sizeof(gpdla_model));
+  printf("sizeof gpdla_samples %zu\n", sizeof(gpdla_samples));
+  printf("sizeof gpdla_spectra %zu\n", sizeof(gpdla_spectra));
+  printf("sizeof gpdla_config %zu\n", sizeof(gpdla_config));
+  printf("sizeof gpdla_results %zu\n", sizeof(gpdla_results));
+  printf("sizeof gpdla_results_multi %zu\n", sizeof(gpdla_results_multi));
+  OFF(gpdla_model, rest_wavelengths); OFF(gpdla_model, log_c_0); OFF(gpdla_model, log_beta);
+  OFF(gpdla_samples, lls_nhi_samples);
+  OFF(gpdla_spectra, pixel_mask); OFF(gpdla_spectra, log_priors_lls);
+  OFF(gpdla_config, width); OFF(gpdla_config, max_dlas); OFF(gpdla_config, min_z_separation);
+  OFF(gpdla_config, rng_seed); OFF(gpdla_config, contraction_precision);
+  OFF(gpdla_config, multi_profile_bytes);
+  OFF(gpdla_results, status); OFF(gpdla_results, MAP_log_nhis);
+  OFF(gpdla_results_multi, base_sample_inds); OFF(gpdla_results_multi, status);
+  gpdla_config cfg;
+  memset(&cfg, 0xAB, sizeof cfg);
+  gpdla_default_config(&cfg);
+  if (gpdla_abi_version() != GPDLA_ABI_VERSION) return 2;
+  if (cfg.width != 3 || cfg.num_lines != 3 || cfg.max_dlas != 4 || cfg.min_lambda != 911.75) return 3;
+  if (cfg.multi_profile_bytes != 0) return 4;
+  uint32_t ctr[4] = {0, 0, 0, 0}, key[2] = {0, 0}, out[4];
+  gpdla_debug_philox4x32_10(ctr, key, out);
+  if (out[0] != 0x6627e8d5u) return 5;
+  /* argument validation needs no GPU */
+  double lam[6] = {1, 2, 3, 4, 5, 6}, prof[1];
+  if (gpdla_voigt(lam, 6, 2.0, 1e20, 3, prof, 0) != GPDLA_ERR_INVALID_ARGUMENT) return 6;
+  printf("GPDLA_SUMMARY_COLS %d\n", GPDLA_SUMMARY_COLS);
+  printf("GPDLA_SUMMARY_COLS_MULTI4 %d\n", GPDLA_SUMMARY_COLS_MULTI(4));
+  return 0;
+}
+"""
+
+
+def test_c_consumer_links_against_the_header(lib, tmp_path):
+    """include/gpdla.h compiles as C99, a C program links against libgpdla.so through it, and the
+    struct layouts the C compiler produces equal the ctypes mirrors the Python host side uses."""
+    import subprocess
+    src = tmp_path / "consumer.c"
+    src.write_text(C_CONSUMER)
+    exe = tmp_path / "consumer"
+    hip_rt = os.path.dirname(_lib._preload_hip_runtime()._name)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe), _lib.LIB_PATH, "-L", hip_rt, "-lamdhip64",
+                    f"-Wl,-rpath,{os.path.dirname(_lib.LIB_PATH)}", f"-Wl,-rpath,{hip_rt}"],
+                   check=True, capture_output=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+    seen = dict(line.rsplit(" ", 1) for line in res.stdout.strip().splitlines())
+    mirrors = {"gpdla_model": _lib.Model, "gpdla_samples": _lib.Samples, "gpdla_spectra": _lib.Spectra,
+               "gpdla_config": _lib.Config, "gpdla_results": _lib.Results,
+               "gpdla_results_multi": _lib.ResultsMulti}
+    for cname, mirror in mirrors.items():
+        assert int(seen[f"sizeof {cname}"]) == C.sizeof(mirror), cname
+    for key, val in seen.items():
+        if "." in key:
+            cname, field = key.split(".")
+            assert int(val) == getattr(mirrors[cname], field).offset, key
+    assert int(seen["GPDLA_SUMMARY_COLS"]) == _lib.SUMMARY_COLS
+    assert int(seen["GPDLA_SUMMARY_COLS_MULTI4"]) == _lib.summary_cols_multi(4) == 78
+
+
+def test_philox4x32_10_known_answers(lib):
+    """The generator behind the multi-DLA resampling (multi :467-472 stand-in) against the
+    Random123 known-answer vectors (kat_vectors: philox4x32 10), and against an independent
+    Python implementation on random counters/keys."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+
+    def lib_philox(ctr, key):
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        lib.gpdla_debug_philox4x32_10(c, k, o)
+        return list(o)
+
+    def py_philox(ctr, key):
+        c, k = list(ctr), list(key)
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+            k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+        return c
+
+    for ctr, key, want in kat:
+        assert lib_philox(ctr, key) == want
+        assert py_philox(ctr, key) == want
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        ctr = [int(x) for x in rng.integers(0, 2**32, 4)]
+        key = [int(x) for x in rng.integers(0, 2**32, 2)]
+        assert lib_philox(ctr, key) == py_philox(ctr, key)
 
 
 def test_argument_validation_needs_no_gpu(lib):
