@@ -5,18 +5,27 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path (gpdla_batch_process: selection + interpolation, null
-evidence, S-sample Voigt/low-rank sweep, evidence + posteriors) over one HBM-resident batch of
-synthetic quasars, followed -- when N > 1 -- by the RCCL all-gather of the posterior table.
-Workload = BASELINE.json configs[1]: 1000 synthetic spectra x n = 1500 pixels x k = 20 x
-S = 10 000 DLA samples, fp64, per GPU (weak scaling: every rank sweeps its own 1000 quasars, as a
-DR12Q run would shard its 162 861).  value = sample log-likelihood evaluations per second over
-all ranks.  Rank 0 prints ONE JSON line.
+evidence, S-sample Voigt/low-rank sweep, evidence + posteriors + MAP) over one HBM-resident batch
+of synthetic quasars, followed -- when N > 1 -- by the RCCL all-gather of the posterior table.
+
+Workloads (--workload):
+  configs1    (default, the headline) BASELINE.json configs[1]: 1000 synthetic spectra x n = 1500
+              pixels x k = 20 x S = 10 000 DLA samples, fp64, per GPU.
+  dr12q-mix   the real shape of a DR12Q run: every spectrum distinct, on the BOSS 1e-4-dex pixel
+              grid (283 .. 1250 pixels in the modelled range, set by z_qso), 5 % of the pixels
+              masked, z_qso spread like the catalogue's.  Same metric; the roofline numerator sums
+              the per-quasar flops F(n_kept, k).
+Weak scaling: every rank sweeps its own --spectra quasars, as a DR12Q run would shard its 162 861.
+value = sample log-likelihood evaluations per second over all ranks.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
+import math
 import os
+import re
 import sys
 import time
 
@@ -30,56 +39,128 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 2048 flop / 64 cycles x 2.4 GH
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md (study variant only)
 
 
-def algorithmic_flops(n: int, k: int) -> float:
+def algorithmic_flops(n, k: int):
     """n k (k+3) + k^3/3 flops per log-likelihood evaluation."""
     return n * k * (k + 3) + k ** 3 / 3.0
+
+
+def lib_sha256() -> str:
+    from gp_dla_detection_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
 
 
 def pmc_traffic(args):
     """HBM bytes per k_sweep launch from the committed rocprofv3 --pmc summary (separate counter
     passes, FETCH_SIZE doubled per the gfx950 rule; profiles/pmc_latest.json).  PMC collection
     cannot run inside this process, so the figure is reported only when it was measured on the
-    same workload shape; otherwise null."""
+    same workload AND on the very libgpdla.so that is loaded now (sha256 recorded by
+    tools/pmc_to_json.py); otherwise null."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
             p = json.load(f)
         c = p["config"]
-        if (c["spectra"], c["pixels"], c["k"], c["dla_samples"]) == (args.spectra, args.pixels, args.k,
-                                                                     args.samples):
-            return float(p["hbm_bytes_per_launch"])
+        same = (c.get("workload", "configs1"), c["spectra"], c["k"], c["dla_samples"]) == (
+            args.workload, args.spectra, args.k, args.samples)
+        if same and p.get("lib_sha256") == lib_sha256():
+            return float(p["hbm_bytes_per_launch"]), p.get("tag")
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
 
 
-def cpu_baseline(model, samples, spectra, seconds_target=12.0):
+def host_cpu_info() -> dict:
+    """Logical CPUs this process may run on, physical cores among them, and the cgroup CPU quota
+    (a GPU box hands one GPU's share of a large host to the job: the quota, not nproc, bounds what
+    OpenMP can use)."""
+    affinity = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count()))
+    info = {"logical_cpus": len(affinity), "cpu_model": None, "cores_physical": None, "cpu_quota": None}
+    try:
+        cores, model, cur = set(), None, {}
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().splitlines() + [""]:
+                if not line.strip():
+                    if "processor" in cur and int(cur["processor"]) in set(affinity):
+                        cores.add((cur.get("physical id", "0"), cur.get("core id", cur["processor"])))
+                    cur = {}
+                    continue
+                key, _, val = line.partition(":")
+                cur[key.strip()] = val.strip()
+                if key.strip() == "model name":
+                    model = val.strip()
+        info["cores_physical"], info["cpu_model"] = len(cores) or None, model
+    except OSError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    info["cpu_quota"] = int(txt[0]) / int(txt[1])
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        info["cpu_quota"] = q / int(f.read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return info
+
+
+def cpu_baseline(model, samples, spectra, seconds_target=6.0, repeats=3):
     """The CPU oracle (literal as-written restatement of the reference path, OpenMP over samples
-    like the reference's parfor) timed on this host: a bounded sample of the same workload --
-    whole quasars (all S samples each) until about `seconds_target` seconds have been spent."""
+    like the reference's parfor, process_qsos.m:185) timed on this host: the timing build of the
+    same source (-O3 -march=native, compiled here; same operations in the same order as the
+    checker build, verified below), on a bounded sample of the same workload -- whole quasars
+    (all S samples each) -- `repeats` times; the median rate is reported.  Threads = physical
+    cores available to this job (capped by the cgroup CPU quota)."""
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    info = host_cpu_info()
+    threads = info["cores_physical"] or info["logical_cpus"]
+    if info["cpu_quota"]:
+        threads = max(1, min(threads, int(math.floor(info["cpu_quota"] + 1e-9))))
     S = samples["offset_samples"].size
+    lib = oracle.load_timing()
 
-    def run(sp, count, threads):
+    def run(sp, count, nthreads, use=lib):
         t0 = time.perf_counter()
-        oracle.process_spectrum(model, samples["offset_samples"][:count], samples["nhi_samples"][:count],
-                                sp["wavelengths"], sp["flux"], sp["noise_variance"],
-                                sp["pixel_mask"], sp["z_qso"], num_threads=threads)
-        return time.perf_counter() - t0
+        r = oracle.process_spectrum(model, samples["offset_samples"][:count], samples["nhi_samples"][:count],
+                                    sp["wavelengths"], sp["flux"], sp["noise_variance"],
+                                    sp["pixel_mask"], sp["z_qso"], num_threads=nthreads, lib=use)
+        return time.perf_counter() - t0, r
 
-    run(spectra[0], min(S, 4 * cores), cores)  # warm up the thread pool
-    done, spent = 0, 0.0
-    while spent < seconds_target and done < len(spectra):
-        spent += run(spectra[done], S, cores)
-        done += 1
-    one_count = min(S, 64)
-    t1 = run(spectra[0], one_count, 1)
-    return dict(value=done * S / spent, unit="evals/s", cores=int(cores), kind="port",
-                single_core_value=one_count / t1,
-                sample=f"{done} quasar(s) n={spectra[0]['wavelengths'].size - 4} x all {S} samples, "
-                       f"{spent:.1f} s, OpenMP over samples on {cores} threads; "
-                       f"single_core_value from {one_count} samples on 1 thread")
+    # the timing build computes what the checker build computes
+    _, a = run(spectra[0], 32, 1)
+    _, b = run(spectra[0], 32, 1, use=oracle.load())
+    same = float(np.nanmax(np.abs(a["sample_log_likelihoods_dla"] - b["sample_log_likelihoods_dla"])))
+    t_probe, _ = run(spectra[0], min(S, 8 * threads), threads)  # also warms the thread pool
+    rate_guess = min(S, 8 * threads) / t_probe
+    per_repeat = max(1, min(len(spectra), int(round(seconds_target * rate_guess / S))))
+    rates, spent_all = [], 0.0
+    for r in range(repeats):
+        spent = 0.0
+        for q in range(per_repeat):
+            spent += run(spectra[(r * per_repeat + q) % len(spectra)], S, threads)[0]
+        rates.append(per_repeat * S / spent)
+        spent_all += spent
+    one_count = min(S, 256)
+    t1 = min(run(spectra[0], one_count, 1)[0] for _ in range(3))
+    single = one_count / t1
+    value = float(np.median(rates))
+    n_desc = sorted({int(np.asarray(s["wavelengths"]).size) for s in spectra[:per_repeat * repeats]})
+    return dict(value=value, unit="evals/s", cores=int(threads), kind="port",
+                cores_physical=info["cores_physical"], logical_cpus=info["logical_cpus"],
+                cpu_quota=info["cpu_quota"], cpu_model=info["cpu_model"], threads=int(threads),
+                repeats=repeats, rates=[float(x) for x in rates], single_core_value=single,
+                parallel_efficiency=value / (threads * single),
+                build="gcc -O3 -march=native -fopenmp -ffp-contract=off (oracle/Makefile `timing`); "
+                      f"max |delta| vs the checker build {same:.1e}",
+                sample=f"{repeats} x {per_repeat} quasar(s) ({n_desc[0]}..{n_desc[-1]} stored pixels) x all {S} "
+                       f"samples, {spent_all:.1f} s in total, OpenMP over samples on {threads} threads; "
+                       f"single_core_value from {one_count} samples on 1 thread (best of 3)")
 
 
 def main():
@@ -87,8 +168,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["configs1", "dr12q-mix"], default="configs1")
     ap.add_argument("--spectra", type=int, default=1000, help="quasars per GPU per step")
-    ap.add_argument("--pixels", type=int, default=1500)
+    ap.add_argument("--pixels", type=int, default=1500, help="configs1 only")
     ap.add_argument("--samples", type=int, default=10000)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--contraction", choices=["f64", "f32"], default="f64",
@@ -126,11 +208,16 @@ def main():
 
     model = synthetic.make_model(args.k)
     samples = synthetic.make_samples(args.samples)
-    # distinct spectra per rank; only a few distinct realisations are generated and tiled (the
-    # sweep's cost does not depend on the flux values)
-    distinct = min(args.spectra, 16)
-    base = synthetic.make_spectra(distinct, args.pixels, model, first_index=1000 * rank)
-    spectra = [base[i % distinct] for i in range(args.spectra)]
+    if args.workload == "configs1":
+        # distinct spectra per rank; only a few distinct realisations are generated and tiled (the
+        # sweep's cost does not depend on the flux values)
+        distinct = min(args.spectra, 16)
+        base = synthetic.make_spectra(distinct, args.pixels, model, first_index=1000 * rank)
+        spectra = [base[i % distinct] for i in range(args.spectra)]
+        n_kept = np.full(args.spectra, args.pixels)
+    else:
+        spectra = synthetic.make_dr12q_mix(args.spectra, model, first_index=args.spectra * rank)
+        n_kept = synthetic.kept_pixel_counts(spectra)
     cat = synthetic.make_prior_catalog()
     z = np.array([s["z_qso"] for s in spectra])
     lp = gp.dla_existence_prior(cat["z_qsos"], cat["dla_ind"], z)
@@ -148,8 +235,7 @@ def main():
         with torch.cuda.stream(stream):
             batch.process()
             if world > 1:
-                table = batch.summary_tensor()
-                gather_summaries(table.cpu() if rehearsal else table, counts)
+                gather_summaries(batch.summary_tensor(), counts)
 
     def fence():
         torch.cuda.synchronize()
@@ -178,12 +264,17 @@ def main():
     evals_per_step = args.spectra * args.samples
     total_evals = evals_per_step * world * args.steps
     value = total_evals / elapsed
-    flops = algorithmic_flops(args.pixels, args.k) * evals_per_step
+    flops = float(np.sum(algorithmic_flops(n_kept.astype(np.float64), args.k))) * args.samples
     achieved = flops / (sweep_ms * 1e-3) / 1e12
     peak = FP64_MFMA_PEAK_TFLOPS if args.contraction == "f64" else FP32_MFMA_PEAK_TFLOPS
 
     out = None
     if rank == 0:
+        traffic, traffic_tag = pmc_traffic(args)
+        workload = ("BASELINE configs[1]: synthetic spectra, fused Voigt + low-rank log-evidence sweep, "
+                    "HBM-resident" if args.workload == "configs1" else
+                    "dr12q-mix: distinct synthetic spectra on the BOSS pixel grid (DR12Q length mix, "
+                    "5 % masked), fused Voigt + low-rank log-evidence sweep, HBM-resident")
         out = {
             "metric": "sample log-likelihoods/sec (n~1500,k=20)",
             "value": value,
@@ -197,17 +288,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if args.contraction == "f64" else "f32 contraction, f64 elsewhere",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic spectra, fused Voigt + low-rank "
-                                   "log-evidence sweep, HBM-resident",
-                       "spectra_per_gpu": args.spectra, "pixels": args.pixels, "k": args.k,
-                       "dla_samples": args.samples, "num_lines": 3,
+            "config": {"workload": workload, "spectra_per_gpu": args.spectra,
+                       "pixels": args.pixels if args.workload == "configs1" else
+                       {"kept_min": int(n_kept.min()), "kept_mean": float(n_kept.mean()),
+                        "kept_max": int(n_kept.max())},
+                       "k": args.k, "dla_samples": args.samples, "num_lines": 3,
                        "parallelism": f"spectra sharded over {world} GPU(s), RCCL all-gather of "
-                                      "the 12-column posterior table"},
+                                      "the 15-column posterior table"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(args), "traffic_unit": "bytes/launch (rocprofv3 PMC, "
-                         "profiles/pmc_latest.json)", "kernel": "k_sweep", "kernel_ms": sweep_ms,
-                         "flops_per_eval": algorithmic_flops(args.pixels, args.k)},
+                         "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, "
+                         f"profiles/pmc_latest.json{', tag ' + traffic_tag if traffic_tag else ''}; null unless "
+                         "measured on this libgpdla.so and workload)", "kernel": "k_sweep",
+                         "kernel_ms": sweep_ms,
+                         "flops_per_launch": flops,
+                         "flops_per_eval": algorithmic_flops(float(n_kept.mean()), args.k)},
         }
         if args.contraction == "f32":
             nchk = min(args.spectra, 4)

@@ -160,6 +160,7 @@ struct gpdla_batch {
   uint8_t *d_mask = nullptr;
   double *d_lp_no = nullptr, *d_lp_dla = nullptr;
   QuasarMeta *d_meta = nullptr;
+  int32_t *d_order = nullptr;  // quasar indices by decreasing pixel count (dealing order of k_sweep)
   PixelRow *d_pix = nullptr;
   double *d_Mi = nullptr, *d_lam = nullptr, *d_records = nullptr;
   double *d_sample_ll = nullptr, *d_ll_no = nullptr, *d_summary = nullptr;
@@ -382,6 +383,7 @@ void gpdla_batch_destroy(gpdla_batch *b) {
   dev_free(b->d_lp_no);
   dev_free(b->d_lp_dla);
   dev_free(b->d_meta);
+  dev_free(b->d_order);
   dev_free(b->d_pix);
   dev_free(b->d_Mi);
   dev_free(b->d_lam);
@@ -453,6 +455,12 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
     chk(upload(&b->mb->lp_lls, sp->log_priors_lls, (size_t)nq, st));
   }
   chk(upload(&b->d_meta, meta.data(), (size_t)nq, st));
+  std::vector<int32_t> order((size_t)nq);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+    return off[x + 1] - off[x] > off[y + 1] - off[y];
+  });
+  chk(upload(&b->d_order, order.data(), (size_t)nq, st));
   chk(dev_alloc(&b->d_pix, (size_t)rows));
   chk(dev_alloc(&b->d_Mi, (size_t)rows * b->k));
   chk(dev_alloc(&b->d_lam, (size_t)lam));
@@ -588,6 +596,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.offset_samples = c->d_offset;
   sa.nhi_samples = c->d_nhi;
   sa.perm = c->d_perm;
+  sa.order = b->d_order;
   sa.S = b->S;
   sa.nq = b->nq;
   sa.k = b->k;

@@ -430,6 +430,7 @@ struct SweepArgs {
   const double *offset_samples;   // [S]
   const double *nhi_samples;      // [S]
   const int32_t *perm;            // [S] sample indices in ascending offset (= z_DLA) order
+  const int32_t *order;           // [nq] quasar indices in order of decreasing pixel count
   int64_t S;
   int64_t nq;
   int32_t blocks_per_quasar;
@@ -913,9 +914,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   constexpr bool kCompact = tiles_compact(NT);  // 13 + 1 tiles on the matrix cores, 2 + 4 columns on the VALU
   using acc_t = typename Mat<T>::acc_t;
   const int64_t xj = blockIdx.x >> 3;
-  const int64_t q = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
+  const int64_t pos = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
   const int bq = (int)(xj % a.blocks_per_quasar);
-  if (q >= a.nq) return;
+  if (pos >= a.nq) return;
+  // quasars are dealt in order of decreasing length (a.order, built at upload), so the eight
+  // quasars in flight -- one per XCD -- are of nearly equal length and the XCDs stay in step
+  const int64_t q = a.order[pos];
   const QuasarMeta m = a.meta[q];
   if (m.status != 0) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

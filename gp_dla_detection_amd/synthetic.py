@@ -110,6 +110,73 @@ def make_spectrum(index: int, n: int, model: dict, params: Parameters | None = N
                 true_z_dla=z_dla, true_log_nhi=log_nhi)
 
 
+BOSS_LOGLAM0, BOSS_NPIX = 3.5563, 4608   # BOSS spectrograph grid: 3600 .. 10400 A at 1e-4 dex
+
+
+def sample_dr12q_redshifts(num: int, seed: int = 4321) -> np.ndarray:
+    """Quasar redshifts shaped like the DR12Q Lyman-alpha-forest sample the reference searches
+    (z_qso >= 2.15, build_catalogs.m; strongly peaked at 2.2 - 2.6 with a tail past 4)."""
+    rng = np.random.default_rng(seed)
+    z = 2.15 + rng.gamma(shape=1.6, scale=0.38, size=num)
+    return np.where(z > 5.8, 2.15 + (z - 2.15) % 3.6, z)
+
+
+def make_boss_spectrum(index: int, z_qso: float, model: dict, params: Parameters | None = None,
+                       mask_fraction: float = 0.05, edge_pixels: int = 2) -> dict:
+    """One synthetic quasar on the BOSS pixel grid (log10 lambda = 3.5563 + 1e-4 j): the modelled
+    rest range [911.75, 1215.75] A covers at most log10(1215.75 / 911.75) / 1e-4 = 1250 pixels and
+    fewer when the spectrograph's blue edge (3600 A) cuts it (z_qso < 2.95) -- the real length mix
+    of a DR12Q run (preload_qsos.m:46 keeps quasars with >= 200 pixels)."""
+    p = params or Parameters()
+    rng = np.random.default_rng(SPECTRUM_SEED0 + 7919 * 1000 + index)
+    loglam = BOSS_LOGLAM0 + p.pixel_spacing * np.arange(BOSS_NPIX)
+    rest_all = 10.0 ** loglam / (1 + z_qso)
+    inside = np.flatnonzero((rest_all >= p.min_lambda) & (rest_all <= p.max_lambda))
+    lo, hi = max(inside[0] - edge_pixels, 0), min(inside[-1] + edge_pixels + 1, BOSS_NPIX)
+    wl = 10.0 ** loglam[lo:hi]
+    rest = wl / (1 + z_qso)
+    k = model["M"].shape[1]
+    grid = model["rest_wavelengths"]
+    mu = np.interp(rest, grid, model["mu"])
+    Mi = np.stack([np.interp(rest, grid, model["M"][:, c]) for c in range(k)], 1)
+    omega2 = np.exp(2 * np.interp(rest, grid, model["log_omega"]))
+    nv = 10.0 ** rng.uniform(-3.0, -1.0, size=wl.size)
+    flux = (mu + Mi @ rng.standard_normal(k)
+            + np.sqrt(omega2 * 0.04 + nv) * rng.standard_normal(wl.size))
+    z_dla = log_nhi = None
+    if index % 2:
+        zmin, zmax = p.min_z_dla(wl, z_qso), p.max_z_dla(wl, z_qso)
+        if zmax > zmin:
+            z_dla = float(rng.uniform(zmin, zmax))
+            log_nhi = float(rng.uniform(20.0, 22.0))
+            flux = flux * _injected_absorption(wl, z_dla, 10.0 ** log_nhi, p.num_lines)
+    mask = (rng.uniform(size=wl.size) < mask_fraction).astype(np.uint8)
+    nv = np.where(mask == 1, np.inf, nv)      # preload_qsos.m: zero inverse variance
+    flux = np.where(mask == 1, np.nan, flux)
+    return dict(wavelengths=wl, flux=flux, noise_variance=nv, pixel_mask=mask, z_qso=float(z_qso),
+                true_z_dla=z_dla, true_log_nhi=log_nhi)
+
+
+def make_dr12q_mix(num: int, model: dict, params: Parameters | None = None,
+                   mask_fraction: float = 0.05, first_index: int = 0, seed: int = 4321) -> list:
+    """``num`` DISTINCT quasars with the DR12Q length mix: redshifts from
+    :func:`sample_dr12q_redshifts`, spectra on the BOSS grid, 5 % of the pixels masked."""
+    z = sample_dr12q_redshifts(first_index + num, seed)[first_index:]
+    return [make_boss_spectrum(first_index + i, float(z[i]), model, params, mask_fraction)
+            for i in range(num)]
+
+
+def kept_pixel_counts(spectra, params: Parameters | None = None) -> np.ndarray:
+    """n of process_qsos.m:110-115 for each quasar (in the rest range and not masked)."""
+    p = params or Parameters()
+    out = np.zeros(len(spectra), dtype=np.int64)
+    for i, s in enumerate(spectra):
+        rest = np.asarray(s["wavelengths"]) / (1 + s["z_qso"])
+        out[i] = np.count_nonzero((rest >= p.min_lambda) & (rest <= p.max_lambda)
+                                  & (np.asarray(s["pixel_mask"]) == 0))
+    return out
+
+
 def make_spectra(num: int, n: int, model: dict, params: Parameters | None = None,
                  mask_fraction: float = 0.0, first_index: int = 0) -> list:
     return [make_spectrum(first_index + i, n, model, params, mask_fraction) for i in range(num)]

@@ -108,23 +108,29 @@ int gpdla_oracle_voigt_raw(const double *lambdas, int64_t num_points, double z, 
 }
 
 /* voigt.c:253-304 */
+static int voigt_ws(const double *lambdas, int64_t num_points, double z, double N, int num_lines,
+                    double *profile, double *raw_profile);
+
 int gpdla_oracle_voigt(const double *lambdas, int64_t num_points, double z, double N,
                        int num_lines, double *profile) {
+  if (num_points <= 2 * GPDLA_CONV_WIDTH) return -1;
+  double *raw_profile = (double *)malloc((size_t)num_points * sizeof(double)); /* voigt.c:275 */
+  int rc = voigt_ws(lambdas, num_points, z, N, num_lines, profile, raw_profile);
+  free(raw_profile);                                                           /* voigt.c:302 */
+  return rc;
+}
+
+static int voigt_ws(const double *lambdas, int64_t num_points, double z, double N, int num_lines,
+                    double *profile, double *raw_profile) {
   const int width = GPDLA_CONV_WIDTH;
-  if (num_points <= 2 * width) return -1;
-  double *raw_profile = (double *)malloc((size_t)num_points * sizeof(double));
   int rc = gpdla_oracle_voigt_raw(lambdas, num_points, z, N, num_lines, raw_profile);
-  if (rc) {
-    free(raw_profile);
-    return rc;
-  }
+  if (rc) return rc;
   int64_t num_out = num_points - 2 * width; /* voigt.c:271, :294 */
   for (int64_t i = 0; i < num_out; i++) {   /* voigt.c:297-299; output starts zero-filled (:271) */
     double acc = 0.0;
     for (int64_t j = i, k = 0; j <= i + 2 * width; j++, k++) acc += raw_profile[j] * instrument_profile[k];
     profile[i] = acc;
   }
-  free(raw_profile);
   return 0;
 }
 
@@ -132,16 +138,26 @@ int gpdla_oracle_voigt(const double *lambdas, int64_t num_points, double z, doub
  * log_mvnpdf_low_rank.m:5-34, as written (including the k x n matrix C of :26).
  * MATLAB's chol returns upper-triangular R with R'R = B (:24).
  * ------------------------------------------------------------------------------------------ */
-int gpdla_oracle_log_mvnpdf_low_rank(const double *y_in, const double *mu, const double *M,
-                                     const double *d, int64_t n, int k, double *log_p) {
+/* doubles of scratch the evaluation needs (y, D_inv_y: n each; D_inv_M, C: n k each; B, R: k k
+ * each; Cy: k) */
+size_t gpdla_oracle_lowrank_scratch_doubles(int64_t n, int k) {
+  return 2 * (size_t)n + 2 * (size_t)n * k + 2 * (size_t)k * k + (size_t)k;
+}
+
+/* The evaluation proper, on caller-provided scratch (so that a sweep allocates once per thread,
+ * not once per sample: at n = 1500 each of these arrays is past glibc's mmap threshold, and 7
+ * mmap/munmap pairs per sample serialise every thread on the kernel's address-space lock). */
+static int lowrank_ws(const double *y_in, const double *mu, const double *M, const double *d,
+                      int64_t n, int k, double *log_p, double *ws) {
   const double log_2pi = 1.83787706640934534; /* :7 */
-  double *y = (double *)malloc(sizeof(double) * (size_t)n);
-  double *D_inv_y = (double *)malloc(sizeof(double) * (size_t)n);
-  double *D_inv_M = (double *)malloc(sizeof(double) * (size_t)n * k);
-  double *B = (double *)calloc((size_t)k * k, sizeof(double));
-  double *R = (double *)calloc((size_t)k * k, sizeof(double));
-  double *C = (double *)malloc(sizeof(double) * (size_t)n * k); /* k x n, column-major */
-  double *Cy = (double *)calloc((size_t)k, sizeof(double));
+  double *y = ws;
+  double *D_inv_y = y + n;
+  double *D_inv_M = D_inv_y + n;
+  double *C = D_inv_M + (size_t)n * k; /* k x n, column-major */
+  double *B = C + (size_t)n * k;
+  double *R = B + (size_t)k * k;
+  double *Cy = R + (size_t)k * k;
+  memset(B, 0, sizeof(double) * ((size_t)2 * k * k + k)); /* B, R, Cy start at zero */
   int rc = 0;
 
   for (int64_t i = 0; i < n; i++) y[i] = y_in[i] - mu[i]; /* :11 */
@@ -176,7 +192,7 @@ int gpdla_oracle_log_mvnpdf_low_rank(const double *y_in, const double *mu, const
   }
   if (rc) {
     *log_p = NAN;
-    goto done;
+    return rc;
   }
   /* :26  C = R \ (R' \ D_inv_M')  -- one column (pixel) at a time */
   for (int64_t i = 0; i < n; i++) {
@@ -208,14 +224,14 @@ int gpdla_oracle_log_mvnpdf_low_rank(const double *y_in, const double *mu, const
   for (int a = 0; a < k; a++) sld += log(R[a + a * k]);
   log_det_K += 2 * sld;
   *log_p = -0.5 * (quad + log_det_K + (double)n * log_2pi); /* :32 */
-done:
-  free(y);
-  free(D_inv_y);
-  free(D_inv_M);
-  free(B);
-  free(R);
-  free(C);
-  free(Cy);
+  return rc;
+}
+
+int gpdla_oracle_log_mvnpdf_low_rank(const double *y_in, const double *mu, const double *M,
+                                     const double *d, int64_t n, int k, double *log_p) {
+  double *ws = (double *)malloc(sizeof(double) * gpdla_oracle_lowrank_scratch_doubles(n, k));
+  int rc = lowrank_ws(y_in, mu, M, d, n, k, log_p, ws);
+  free(ws);
   return rc;
 }
 
@@ -335,13 +351,18 @@ static void z_dla_range(const gpdla_oracle_params *prm, const selection *s, doub
   *zmin = a > b ? a : b;
 }
 
+static size_t sample_scratch_doubles(int64_t n, int k) {
+  return (size_t)n * (2 + k) + gpdla_oracle_lowrank_scratch_doubles(n, k);
+}
+
 /* the body of the sweep, process_qsos.m:187-198: one sample's log-likelihood given the (already
  * multiplied, for the multi-DLA driver) absorption on the unmasked grid */
 static double sample_loglik(const selection *s, int k, const double *absorption_u,
                             const double *this_mu, const double *this_M, const double *this_omega2,
-                            double *scratch /* (3 + k) * n doubles */) {
+                            double *scratch /* sample_scratch_doubles(n, k) */) {
   int64_t n = s->n;
   double *dla_mu = scratch, *dla_d = scratch + n, *dla_M = scratch + 2 * n;
+  double *ws = dla_M + (size_t)n * k;
   int64_t j = 0;
   for (int64_t i = 0; i < s->n_u; i++) { /* absorption(ind), :190 */
     if (!s->keep[i]) continue;
@@ -352,7 +373,7 @@ static double sample_loglik(const selection *s, int k, const double *absorption_
     j++;
   }
   double lp;
-  gpdla_oracle_log_mvnpdf_low_rank(s->flux, dla_mu, dla_M, dla_d, n, k, &lp); /* :196-198 */
+  lowrank_ws(s->flux, dla_mu, dla_M, dla_d, n, k, &lp, ws); /* :196-198 */
   return lp;
 }
 
@@ -438,16 +459,20 @@ int gpdla_oracle_process_spectrum(const gpdla_oracle_params *prm, const gpdla_or
 #endif
 #pragma omp parallel
   {
+    /* per-thread scratch, allocated once outside the sample loop (a MATLAB parfor worker likewise
+     * keeps its heap); the operations per sample are unchanged */
     double *absorption = (double *)malloc(sizeof(double) * (size_t)s.n_u);
-    double *scratch = (double *)malloc(sizeof(double) * (size_t)n * (3 + k));
+    double *raw = (double *)malloc(sizeof(double) * (size_t)n_pad);
+    double *scratch = (double *)malloc(sizeof(double) * sample_scratch_doubles(n, k));
 #pragma omp for schedule(static)
     for (int64_t i = 0; i < S; i++) { /* parfor, :185 */
       double z_dla = *min_z_dla + (*max_z_dla - *min_z_dla) * offset_samples[i]; /* :162-164 */
       if (dump && dump->sample_z_dlas) dump->sample_z_dlas[i] = z_dla;
-      gpdla_oracle_voigt(padded, n_pad, z_dla, nhi_samples[i], prm->num_lines, absorption); /* :187 */
+      voigt_ws(padded, n_pad, z_dla, nhi_samples[i], prm->num_lines, absorption, raw); /* :187 */
       sample_ll[i] = sample_loglik(&s, k, absorption, this_mu, this_M, this_omega2, scratch);
     }
     free(absorption);
+    free(raw);
     free(scratch);
   }
   *log_likelihood_dla = log_mean_exp(sample_ll, S, 0, NULL); /* :203-210 */
@@ -551,23 +576,25 @@ int gpdla_oracle_process_spectrum_multi(
     {
       double *absorption = (double *)malloc(sizeof(double) * (size_t)s.n_u);
       double *other = (double *)malloc(sizeof(double) * (size_t)s.n_u);
-      double *scratch = (double *)malloc(sizeof(double) * (size_t)n * (3 + k));
+      double *raw = (double *)malloc(sizeof(double) * (size_t)n_pad);
+      double *scratch = (double *)malloc(sizeof(double) * sample_scratch_doubles(n, k));
 #pragma omp for schedule(static)
       for (int64_t i = 0; i < S; i++) { /* parfor, multi :340 */
-        gpdla_oracle_voigt(padded, n_pad, sample_z[i], nhi_samples[i], prm->num_lines, absorption);
+        voigt_ws(padded, n_pad, sample_z[i], nhi_samples[i], prm->num_lines, absorption, raw);
         for (int j = 1; j <= num_dlas - 1; j++) { /* multi :346-351 */
           int64_t kk = (int64_t)mul->base_sample_inds[(j - 1) + (size_t)i * (max_dlas - 1)] - 1;
-          gpdla_oracle_voigt(padded, n_pad, sample_z[kk], nhi_samples[kk], prm->num_lines, other);
+          voigt_ws(padded, n_pad, sample_z[kk], nhi_samples[kk], prm->num_lines, other, raw);
           for (int64_t p = 0; p < s.n_u; p++) absorption[p] = absorption[p] * other[p];
         }
         col[i] = sample_loglik(&s, k, absorption, this_mu, this_M, this_omega2, scratch) - log_S; /* :359-361 */
         if (num_dlas == 1) { /* multi :365-380 */
-          gpdla_oracle_voigt(padded, n_pad, sample_z[i], mul->lls_nhi_samples[i], prm->num_lines, absorption);
+          voigt_ws(padded, n_pad, sample_z[i], mul->lls_nhi_samples[i], prm->num_lines, absorption, raw);
           sample_ll_lls[i] = sample_loglik(&s, k, absorption, this_mu, this_M, this_omega2, scratch) - log_S;
         }
       }
       free(absorption);
       free(other);
+      free(raw);
       free(scratch);
     }
     if (num_dlas > 1) { /* multi :386-392: any(diff(sort(all_z_dlas)) < min_z_separation) */

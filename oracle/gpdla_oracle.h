@@ -28,6 +28,7 @@
 #ifndef GPDLA_ORACLE_H
 #define GPDLA_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -52,6 +53,8 @@ int gpdla_oracle_voigt_raw(const double *lambdas, int64_t num_points, double z, 
  * (MATLAB's chol would throw, :24); *log_p is NaN then. */
 int gpdla_oracle_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M,
                                      const double *d, int64_t n, int k, double *log_p);
+/* doubles of scratch one evaluation uses (the drivers allocate it once per thread) */
+size_t gpdla_oracle_lowrank_scratch_doubles(int64_t n, int k);
 
 /* Constants of set_parameters.m that the driver reads (process_qsos.m:104-105,118,159-176,188). */
 typedef struct {

@@ -61,12 +61,7 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    build()
-    lib = C.CDLL(_LIB_PATH)
+def _bind(lib):
     lib.gpdla_oracle_faddeeva_re.restype = C.c_double
     lib.gpdla_oracle_faddeeva_re.argtypes = [C.c_double, C.c_double]
     lib.gpdla_oracle_voigt_line.restype = C.c_double
@@ -88,8 +83,29 @@ def load():
     lib.gpdla_oracle_objective.restype = C.c_int
     lib.gpdla_oracle_objective.argtypes = [_dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _dp, C.c_int,
                                            _dp, _dp]
-    _lib = lib
     return lib
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = _bind(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+_timing_lib = None
+
+
+def load_timing():
+    """The timing build of the same source (-O3 -march=native; ``make timing``), compiled ON the
+    machine that calls this -- a -march=native object must not travel between hosts -- for the
+    ``cpu_baseline`` leg of bench.py."""
+    global _timing_lib
+    if _timing_lib is None:
+        subprocess.run(["make", "-B", "-C", _HERE, "timing"], check=True, capture_output=True)
+        _timing_lib = _bind(C.CDLL(os.path.join(_HERE, "_build", "libgpdla_oracle_timing.so")))
+    return _timing_lib
 
 
 def _d(a):
@@ -175,9 +191,10 @@ def _model_struct(model):
 
 def process_spectrum(model, offset_samples, nhi_samples, wavelengths, flux, noise_variance,
                      pixel_mask, z_qso, params: OracleParams | None = None, num_threads=0,
-                     dump=False):
-    """process_qsos.m:96-213 for one quasar.  Returns a dict (plus intermediates if dump)."""
-    lib = load()
+                     dump=False, lib=None):
+    """process_qsos.m:96-213 for one quasar.  Returns a dict (plus intermediates if dump).
+    ``lib``: the build to call (default: the checker build; bench.py passes the timing build)."""
+    lib = lib or load()
     params = params or OracleParams()
     prm = params.c()
     mdl, keep = _model_struct(model)

@@ -1,12 +1,13 @@
 """Merge the rocprofv3 --pmc passes of tools/profile.sh into one JSON summary for k_sweep.
 
-usage: pmc_to_json.py <gpurun_out dir> <tag>
+usage: pmc_to_json.py <gpurun_out dir> <tag> [workload]
 FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB (rocprofv3 derived counters); FETCH_SIZE is
 doubled for gfx950 (MI355X_MICROARCH.md, HBM section: wide coalesced streaming reads are reported at
 half their bytes); WRITE_SIZE is taken as read.
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -14,6 +15,19 @@ import sys
 
 def main():
     out, tag = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "configs1"
+    # bench.py's own line from one of the counter passes says what shape was run
+    bench = {}
+    for log in sorted(glob.glob(os.path.join(out, f"pmc_{tag}_*.log"))):
+        try:
+            bench = json.loads(open(log).read().strip().splitlines()[-1])
+            break
+        except (ValueError, IndexError):
+            continue
+    cfg = bench.get("config", {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "gp_dla_detection_amd", "csrc", "libgpdla.so"), "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
     counters, launches, kernel = {}, {}, None
     for path in glob.glob(os.path.join(out, f"pmc_{tag}_*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
@@ -25,9 +39,12 @@ def main():
                 counters[c] = counters.get(c, 0.0) + float(row["Counter_Value"])
                 launches[c] = launches.get(c, 0) + 1
     per_launch = {c: counters[c] / launches[c] for c in sorted(counters)}
-    # tools/profile.sh runs bench.py with its defaults: BASELINE configs[1]
-    res = {"kernel": kernel,
-           "config": {"spectra": 1000, "pixels": 1500, "k": 20, "dla_samples": 10000, "num_lines": 3}, "launches_per_counter": launches, "counters_per_launch": per_launch,
+    res = {"kernel": kernel, "tag": tag, "lib_sha256": sha,
+           "config": {"workload": workload, "spectra": cfg.get("spectra_per_gpu", 1000),
+                      "pixels": cfg.get("pixels", 1500), "k": cfg.get("k", 20),
+                      "dla_samples": cfg.get("dla_samples", 10000), "num_lines": 3},
+           "flops_per_launch": bench.get("roofline", {}).get("flops_per_launch"),
+           "launches_per_counter": launches, "counters_per_launch": per_launch,
            "note": "separate --pmc passes (tools/profile.sh); FETCH_SIZE doubled for gfx950, WRITE_SIZE as read; "
                    "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in "
                    "cycles, GRBM_GUI_ACTIVE summed over the 8 XCDs"}
