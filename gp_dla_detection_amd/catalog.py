@@ -63,3 +63,81 @@ def write_results(path: str, thing_ids, results: dict, samples: dict) -> None:
                 results["log_likelihoods_no_dla"][i], results["log_likelihoods_dla"][i],
                 _e3(mp[i, 0]), _e3(mp[i, 1])))
             f.write("%06.4f %07.4f\n" % (z_map[i], n_map[i]))
+
+
+# ----------------------------------------------------------------------------------------------
+# JSON catalogues of the multi-DLA run (CDDF_analysis/qso_loader.py:1927-2094)
+# ----------------------------------------------------------------------------------------------
+
+_INFO_FIELDS = (("ra", "ras"), ("snr", "snrs"), ("dec", "decs"), ("plate", "plates"), ("mjd", "mjds"),
+                ("fiber_id", "fiber_ids"), ("thing_id", "thing_ids"), ("z_qso", "z_qsos"))
+
+
+def _py(x):
+    """numpy scalar -> Python scalar (json cannot serialise numpy types; the reference calls .item())."""
+    return x.item() if hasattr(x, "item") else x
+
+
+def generate_json_catalogue(results: dict, quasar_info: dict, outfile: str | None = None,
+                            sub_dla: bool = True) -> list:
+    """``QSOLoader.generate_json_catalogue`` (qso_loader.py:1927-2031): one record per searched
+    quasar in the form of Parks et al. (2018) -- ``p_dla, p_no_dla, max_model_posterior, num_dlas,
+    dlas: [{log_nhi, z_dla}], min_z_dla, max_z_dla, ra, snr, dec, plate, mjd, fiber_id, thing_id,
+    z_qso`` -- from the multi-DLA results (``model_posteriors`` [nq, 2+max_dlas] = (no DLA, sub-DLA,
+    1..max_dlas DLAs), ``MAP_z_dlas`` / ``MAP_log_nhis`` [nq, model, slot]).  ``quasar_info``:
+    ``ras, decs, plates, mjds, fiber_ids, thing_ids, z_qsos, snrs`` of the searched quasars (the
+    catalogue columns after the ``test_ind`` subset, qso_loader.py:114-125).  With ``sub_dla`` the
+    sub-DLA posterior counts towards "no DLA" (:100-101, :1977-1985)."""
+    mp = np.asarray(results["model_posteriors"], dtype=np.float64)
+    nq = mp.shape[0]
+    p_dlas = np.asarray(results["p_dlas"], dtype=np.float64)
+    p_no = np.asarray(results["p_no_dlas"], dtype=np.float64).copy()
+    if sub_dla:
+        p_no += mp[:, 1]                                             # qso_loader.py:100-101
+    filled = np.where(np.isnan(mp), -np.inf, mp)
+    model_index = filled.argmax(axis=1)                              # :1973
+    max_mp = mp[np.arange(nq), model_index].copy()                   # :1974
+    num_dlas = model_index.copy()
+    if sub_dla:
+        inds = model_index < 2                                       # :1979
+        max_mp[inds] = p_no[inds]                                    # :1980
+        num_dlas = model_index - 1                                   # :1983
+        num_dlas[num_dlas < 0] = 0                                   # :1984
+    map_z, map_n = np.asarray(results["MAP_z_dlas"]), np.asarray(results["MAP_log_nhis"])
+    for _, col in _INFO_FIELDS:
+        if len(quasar_info[col]) != nq:
+            raise ValueError(f"quasar_info[{col!r}] has {len(quasar_info[col])} entries for {nq} quasars")
+    out = []
+    for i in range(nq):
+        spec = {"p_dla": _py(p_dlas[i]), "p_no_dla": _py(p_no[i]), "max_model_posterior": _py(max_mp[i]),
+                "num_dlas": int(num_dlas[i]), "min_z_dla": _py(np.asarray(results["min_z_dlas"])[i]),
+                "max_z_dla": _py(np.asarray(results["max_z_dlas"])[i])}
+        for key, col in _INFO_FIELDS:
+            spec[key] = _py(np.asarray(quasar_info[col])[i])
+        n = int(num_dlas[i])
+        spec["dlas"] = [{"log_nhi": _py(map_n[i, n - 1, j]), "z_dla": _py(map_z[i, n - 1, j])}
+                        for j in range(n)]                           # :2007-2018
+        out.append(spec)
+    if outfile is not None:
+        import json
+        with open(outfile, "w") as f:
+            json.dump(out, f, indent=2)
+    return out
+
+
+def generate_sub_dla_catalogue(results: dict, quasar_info: dict, outfile: str | None = None) -> list:
+    """``QSOLoader.generate_sub_dla_catalogue`` (qso_loader.py:2033-2087): the quasars whose most
+    probable model is the sub-DLA one, with ``p_sub_dla`` and the spectrum identifiers."""
+    mp = np.asarray(results["model_posteriors"], dtype=np.float64)
+    model_index = np.where(np.isnan(mp), -np.inf, mp).argmax(axis=1)
+    out = []
+    for i in np.flatnonzero(model_index == 1):
+        rec = {"p_sub_dla": _py(mp[i, 1])}
+        for key, col in _INFO_FIELDS:
+            rec[key] = _py(np.asarray(quasar_info[col])[i])
+        out.append(rec)
+    if outfile is not None:
+        import json
+        with open(outfile, "w") as f:
+            json.dump(out, f, indent=2)
+    return out

@@ -1,0 +1,940 @@
+"""A minimal HDF5 reader/writer in pure Python (numpy + zlib): the subset MATLAB ``-v7.3`` files use.
+
+Every file the inference path consumes or produces is a MATLAB ``-v7.3`` file, i.e. HDF5 behind a
+512-byte MATLAB header (process_qsos.m:250, learn_qso_model.m:123, preload_qsos.m:79,
+generate_dla_samples.m:63), and the downstream consumer opens the output with ``h5py.File``
+(CDDF_analysis/qso_loader.py:84-112, calc_cddf.py:104).  ``h5py`` / libhdf5 are in neither the
+build image nor the GPU box, so this module implements the on-disk format directly, following the
+"HDF5 File Format Specification Version 2.0" (superblock 0/1 and 2/3, version-1 and version-2
+object headers, symbol-table groups and compact link-message groups, version-1 B-trees, local
+heaps, contiguous / compact / chunked layouts, the deflate, shuffle and fletcher32 filters,
+fixed-point / floating-point / string / object-reference datatypes, attributes).  Not supported,
+and reported as such: dense (fractal-heap) groups, version-4 chunk indices, variable-length and
+compound datatypes, external links.
+
+Reader:  ``File(path)`` -> groups and datasets by name; ``Dataset.read()`` returns a NumPy array
+in HDF5 (row-major) dimension order -- MATLAB stores its column-major arrays with the dimensions
+reversed, so a MATLAB ``[n x m]`` matrix reads back as ``(m, n)``, exactly what ``h5py`` shows.
+Writer:  ``FileWriter(path, userblock=...)``: version-0 superblock, version-1 object headers,
+symbol-table groups -- the layout libhdf5 1.8 (and therefore MATLAB) writes by default, readable
+by every libhdf5 -- with contiguous or chunked+deflate datasets and object references.
+
+The reader is validated against a file written by MATLAB itself (SciPy ships one,
+``scipy/io/matlab/tests/data/testhdf5_7.4_GLNX86.mat``) and against this module's writer; the
+writer against the reader and against byte-level checks of the structures it emits
+(tests/test_hdf5.py).  No libhdf5 was available to cross-read: self-validated.
+"""
+from __future__ import annotations
+
+import mmap
+import struct
+import zlib
+
+import numpy as np
+
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+# header message types
+MSG_NIL, MSG_DATASPACE, MSG_LINK_INFO, MSG_DATATYPE, MSG_FILL_OLD, MSG_FILL, MSG_LINK = 0, 1, 2, 3, 4, 5, 6
+MSG_LAYOUT, MSG_GROUP_INFO, MSG_FILTERS, MSG_ATTRIBUTE, MSG_CONTINUATION, MSG_SYMBOL_TABLE = 8, 0x0A, 0x0B, 0x0C, 0x10, 0x11
+MSG_MTIME = 0x12
+
+
+class HDF5Error(ValueError):
+    pass
+
+
+def _pad8(n: int) -> int:
+    return (n + 7) & ~7
+
+
+# =================================================================================================
+# reader
+# =================================================================================================
+
+class _Datatype:
+    """A decoded datatype message: numpy dtype + whether the elements are object references."""
+
+    def __init__(self, dtype, is_ref=False, is_string=False):
+        self.dtype, self.is_ref, self.is_string = np.dtype(dtype), is_ref, is_string
+
+
+def _parse_datatype(buf, off=0) -> tuple[_Datatype, int]:
+    """Datatype message (spec IV.A.2.d).  Returns (type, bytes consumed)."""
+    cls_ver, b0, b1, b2 = buf[off], buf[off + 1], buf[off + 2], buf[off + 3]
+    cls, size = cls_ver & 0x0F, struct.unpack_from("<I", buf, off + 4)[0]
+    order = ">" if (b0 & 1) else "<"
+    if cls == 0:  # fixed-point
+        if size not in (1, 2, 4, 8):
+            raise HDF5Error(f"fixed-point size {size} not supported")
+        kind = "i" if (b0 & 0x08) else "u"
+        return _Datatype(f"{order}{kind}{size}"), 8 + 4
+    if cls == 1:  # floating-point
+        if size not in (2, 4, 8):
+            raise HDF5Error(f"floating-point size {size} not supported")
+        return _Datatype(f"{order}f{size}"), 8 + 12
+    if cls == 3:  # fixed-length string
+        return _Datatype(f"S{size}", is_string=True), 8
+    if cls == 7:  # reference
+        if (b0 & 0x0F) != 0 or size != 8:
+            raise HDF5Error("only 8-byte object references are supported (no region references)")
+        return _Datatype("<u8", is_ref=True), 8
+    if cls == 8:  # enumeration (h5py booleans): take the base integer type
+        nmembers = b0 | (b1 << 8)
+        base, used = _parse_datatype(buf, off + 8)
+        pos = off + 8 + used
+        version = cls_ver >> 4
+        for _ in range(nmembers):  # names
+            end = buf.index(b"\x00", pos)
+            pos = end + 1 if version >= 3 else pos + _pad8(end + 1 - pos)
+        pos += nmembers * base.dtype.itemsize
+        return base, pos - off
+    names = {2: "time", 4: "bitfield", 5: "opaque", 6: "compound", 9: "variable-length", 10: "array"}
+    raise HDF5Error(f"datatype class {cls} ({names.get(cls, '?')}) is not supported")
+
+
+class _Message:
+    __slots__ = ("type", "flags", "data")
+
+    def __init__(self, type_, flags, data):
+        self.type, self.flags, self.data = type_, flags, data
+
+
+class File:
+    """Read-only view of an HDF5 file (possibly behind a user block, as MATLAB -v7.3 files are)."""
+
+    def __init__(self, path: str):
+        self.path = str(path)
+        self._fh = open(self.path, "rb")
+        try:
+            self._mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError as e:
+            self._fh.close()
+            raise HDF5Error(f"{path}: empty file") from e
+        self.userblock_size = self._find_superblock()
+        self.base = self.userblock_size  # libhdf5 takes the superblock's own position as the base address
+        self._parse_superblock()
+
+    # ---- low level ------------------------------------------------------------------------------
+    def close(self):
+        if self._mm is not None:
+            try:
+                self._mm.close()
+            except BufferError:  # arrays returned with memmap=True still view the file
+                pass
+            self._mm = None
+            self._fh.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _find_superblock(self) -> int:
+        off, size = 0, len(self._mm)
+        while off + 8 <= size:
+            if self._mm[off:off + 8] == SIGNATURE:
+                return off
+            off = 512 if off == 0 else off * 2
+        raise HDF5Error(f"{self.path}: no HDF5 superblock (not a -v7.3 / HDF5 file)")
+
+    def _abs(self, addr: int) -> int:
+        return self.base + addr
+
+    def _bytes(self, addr: int, n: int) -> bytes:
+        a = self._abs(addr)
+        if a + n > len(self._mm):
+            raise HDF5Error(f"{self.path}: read past the end of the file (address {addr}, {n} bytes): truncated?")
+        return self._mm[a:a + n]
+
+    def _parse_superblock(self):
+        mm, sb = self._mm, self.userblock_size
+        version = mm[sb + 8]
+        self.superblock_version = version
+        if version in (0, 1):
+            so, sl = mm[sb + 13], mm[sb + 14]
+            if (so, sl) != (8, 8):
+                raise HDF5Error(f"offsets/lengths of {so}/{sl} bytes are not supported (need 8/8)")
+            self.group_leaf_k, self.group_internal_k = struct.unpack_from("<HH", mm, sb + 16)
+            pos = sb + 24 + (4 if version == 1 else 0)
+            self.stored_base, _, self.eof, _ = struct.unpack_from("<4Q", mm, pos)
+            pos += 32
+            _, root_header, cache, _ = struct.unpack_from("<QQII", mm, pos)
+            self._root_addr = root_header
+        elif version in (2, 3):
+            so, sl = mm[sb + 9], mm[sb + 10]
+            if (so, sl) != (8, 8):
+                raise HDF5Error(f"offsets/lengths of {so}/{sl} bytes are not supported (need 8/8)")
+            self.stored_base, _, self.eof, self._root_addr = struct.unpack_from("<4Q", mm, sb + 12)
+            self.group_leaf_k, self.group_internal_k = 4, 16
+        else:
+            raise HDF5Error(f"superblock version {version} is not supported")
+        if self.eof > len(mm):
+            raise HDF5Error(f"{self.path}: truncated (end-of-file address {self.eof}, file has {len(mm)} bytes)")
+        self.root = Group(self, self._root_addr, "/")
+
+    # ---- object headers -------------------------------------------------------------------------
+    def _messages(self, addr: int) -> list[_Message]:
+        head = self._bytes(addr, 16)
+        if head[:4] == b"OHDR":
+            return self._messages_v2(addr)
+        if head[0] != 1:
+            raise HDF5Error(f"object header version {head[0]} at {addr} is not supported")
+        nmsg, _, first = struct.unpack_from("<HII", head, 2)
+        out: list[_Message] = []
+        blocks = [(addr + 16, first)]
+        while blocks and len(out) < nmsg:
+            baddr, blen = blocks.pop(0)
+            buf = self._bytes(baddr, blen)
+            pos = 0
+            while pos + 8 <= blen and len(out) < nmsg:
+                mtype, msize, mflags = struct.unpack_from("<HHB", buf, pos)
+                data = buf[pos + 8: pos + 8 + msize]
+                pos += 8 + msize
+                if mtype == MSG_CONTINUATION:
+                    blocks.append(struct.unpack_from("<QQ", data))
+                out.append(_Message(mtype, mflags, data))
+        return out
+
+    def _messages_v2(self, addr: int) -> list[_Message]:
+        head = self._bytes(addr, 64)
+        flags = head[5]
+        pos = 6
+        if flags & 0x20:
+            pos += 16
+        if flags & 0x10:
+            pos += 4
+        width = 1 << (flags & 3)
+        chunk0 = int.from_bytes(head[pos:pos + width], "little")
+        pos += width
+        order = 2 if flags & 0x04 else 0
+        out: list[_Message] = []
+        blocks = [(addr + pos, chunk0)]
+        while blocks:
+            baddr, blen = blocks.pop(0)
+            buf = self._bytes(baddr, blen)
+            p = 0
+            while p + 4 + order <= blen:
+                mtype, msize, mflags = struct.unpack_from("<BHB", buf, p)
+                p += 4 + order
+                data = buf[p:p + msize]
+                p += msize
+                if mtype == MSG_CONTINUATION:
+                    caddr, clen = struct.unpack_from("<QQ", data)
+                    blocks.append((caddr + 4, clen - 8))  # skip "OCHK", drop the checksum
+                out.append(_Message(mtype, mflags, data))
+        return out
+
+    def _object(self, addr: int, name: str):
+        msgs = self._messages(addr)
+        types = {m.type for m in msgs}
+        if MSG_LAYOUT in types:
+            return Dataset(self, addr, name, msgs)
+        return Group(self, addr, name, msgs)
+
+    def dereference(self, ref: int):
+        """The object an 8-byte object reference (an object-header address) points to."""
+        return self._object(int(ref), f"<ref {int(ref)}>")
+
+    # ---- mapping interface ----------------------------------------------------------------------
+    def keys(self):
+        return self.root.keys()
+
+    def __contains__(self, name):
+        return name in self.root
+
+    def __getitem__(self, name):
+        return self.root[name]
+
+    @property
+    def attrs(self):
+        return self.root.attrs
+
+    def userblock(self) -> bytes:
+        return bytes(self._mm[: self.userblock_size])
+
+
+def _parse_attribute(f: File, data: bytes):
+    version = data[0]
+    if version == 1:
+        nlen, tlen, slen = struct.unpack_from("<HHH", data, 2)
+        pos = 8
+        name = data[pos:pos + nlen].split(b"\x00")[0].decode()
+        pos += _pad8(nlen)
+        dt, _ = _parse_datatype(data, pos)
+        pos += _pad8(tlen)
+        shape = _parse_dataspace(data[pos:pos + slen])
+        pos += _pad8(slen)
+    elif version in (2, 3):
+        nlen, tlen, slen = struct.unpack_from("<HHH", data, 2)
+        pos = 8 + (1 if version == 3 else 0)
+        name = data[pos:pos + nlen].split(b"\x00")[0].decode()
+        pos += nlen
+        dt, _ = _parse_datatype(data, pos)
+        pos += tlen
+        shape = _parse_dataspace(data[pos:pos + slen])
+        pos += slen
+    else:
+        raise HDF5Error(f"attribute message version {version} is not supported")
+    count = int(np.prod(shape)) if shape else 1
+    arr = np.frombuffer(data, dtype=dt.dtype, count=count, offset=pos).reshape(shape)
+    if dt.is_string:
+        val = arr.reshape(-1)[0].split(b"\x00")[0].decode() if count == 1 else arr
+        return name, val
+    return name, (arr.copy() if shape else arr.reshape(-1)[0])
+
+
+def _parse_dataspace(data: bytes) -> tuple:
+    version, rank, flags = data[0], data[1], data[2]
+    if version == 1:
+        pos = 8
+    elif version == 2:
+        if data[3] == 2:  # null dataspace
+            return (0,)
+        pos = 4
+    else:
+        raise HDF5Error(f"dataspace message version {version} is not supported")
+    return tuple(struct.unpack_from(f"<{rank}Q", data, pos)) if rank else ()
+
+
+class _Node:
+    """Shared: attributes of an object."""
+
+    def __init__(self, f: File, addr: int, name: str, msgs=None):
+        self.file, self.addr, self.name = f, addr, name
+        self._msgs = msgs if msgs is not None else f._messages(addr)
+        self._attrs = None
+
+    @property
+    def attrs(self) -> dict:
+        if self._attrs is None:
+            self._attrs = dict(_parse_attribute(self.file, m.data) for m in self._msgs if m.type == MSG_ATTRIBUTE)
+        return self._attrs
+
+
+class Group(_Node):
+    def __init__(self, f, addr, name, msgs=None):
+        super().__init__(f, addr, name, msgs)
+        self._links = None
+
+    def _load(self):
+        if self._links is not None:
+            return
+        links: dict[str, int] = {}
+        f = self.file
+        for m in self._msgs:
+            if m.type == MSG_SYMBOL_TABLE:
+                btree, heap = struct.unpack_from("<QQ", m.data)
+                hbuf = f._bytes(heap, 32)
+                if hbuf[:4] != b"HEAP":
+                    raise HDF5Error(f"bad local heap signature at {heap}")
+                hsize, _, hdata = struct.unpack_from("<QQQ", hbuf, 8)
+                names = f._bytes(hdata, hsize)
+                self._walk_group_btree(btree, names, links)
+            elif m.type == MSG_LINK:
+                d = m.data
+                flags = d[1]
+                pos = 2
+                ltype = 0
+                if flags & 0x08:
+                    ltype = d[pos]
+                    pos += 1
+                if flags & 0x04:
+                    pos += 8
+                if flags & 0x10:
+                    pos += 1
+                width = 1 << (flags & 3)
+                nlen = int.from_bytes(d[pos:pos + width], "little")
+                pos += width
+                lname = d[pos:pos + nlen].decode()
+                pos += nlen
+                if ltype != 0:
+                    continue  # soft / external links are not followed
+                links[lname] = struct.unpack_from("<Q", d, pos)[0]
+            elif m.type == MSG_LINK_INFO:
+                d = m.data
+                pos = 2 + (8 if d[1] & 1 else 0)
+                fheap = struct.unpack_from("<Q", d, pos)[0]
+                if fheap != UNDEF:
+                    raise HDF5Error("dense (fractal-heap) group storage is not supported; "
+                                    "rewrite the file with libver='earliest'")
+        self._links = links
+
+    def _walk_group_btree(self, addr, names, links):
+        f = self.file
+        if addr == UNDEF:
+            return
+        head = f._bytes(addr, 24)
+        if head[:4] != b"TREE" or head[4] != 0:
+            raise HDF5Error(f"bad group B-tree node at {addr}")
+        level, used = head[5], struct.unpack_from("<H", head, 6)[0]
+        body = f._bytes(addr + 24, (2 * used + 1) * 8)
+        children = struct.unpack_from(f"<{2 * used + 1}Q", body)[1::2]
+        for child in children:
+            if level > 0:
+                self._walk_group_btree(child, names, links)
+                continue
+            sn = f._bytes(child, 8)
+            if sn[:4] != b"SNOD":
+                raise HDF5Error(f"bad symbol table node at {child}")
+            count = struct.unpack_from("<H", sn, 6)[0]
+            ents = f._bytes(child + 8, count * 40)
+            for e in range(count):
+                noff, haddr = struct.unpack_from("<QQ", ents, e * 40)
+                end = names.index(b"\x00", noff)
+                links[names[noff:end].decode()] = haddr
+
+    def keys(self):
+        self._load()
+        return list(self._links)
+
+    def __contains__(self, name):
+        self._load()
+        return name in self._links
+
+    def __len__(self):
+        self._load()
+        return len(self._links)
+
+    def __getitem__(self, name: str):
+        self._load()
+        node = self
+        for part in [p for p in name.split("/") if p]:
+            if not isinstance(node, Group):
+                raise KeyError(name)
+            node._load()
+            if part not in node._links:
+                raise KeyError(f"{name!r} not in {self.name!r} of {self.file.path}")
+            node = self.file._object(node._links[part], part)
+        return node
+
+
+def _unshuffle(buf: bytes, itemsize: int) -> bytes:
+    n = len(buf) // itemsize
+    if itemsize <= 1 or n == 0:
+        return buf
+    a = np.frombuffer(buf, dtype=np.uint8, count=n * itemsize).reshape(itemsize, n)
+    return a.T.tobytes() + buf[n * itemsize:]
+
+
+def _shuffle(buf: bytes, itemsize: int) -> bytes:
+    n = len(buf) // itemsize
+    if itemsize <= 1 or n == 0:
+        return buf
+    a = np.frombuffer(buf, dtype=np.uint8, count=n * itemsize).reshape(n, itemsize)
+    return a.T.tobytes() + buf[n * itemsize:]
+
+
+class Dataset(_Node):
+    def __init__(self, f, addr, name, msgs=None):
+        super().__init__(f, addr, name, msgs)
+        self.shape = ()
+        self._dt = None
+        self._layout = None
+        self._filters = []
+        for m in self._msgs:
+            if m.type == MSG_DATASPACE:
+                self.shape = _parse_dataspace(m.data)
+            elif m.type == MSG_DATATYPE:
+                self._dt, _ = _parse_datatype(m.data)
+            elif m.type == MSG_LAYOUT:
+                self._layout = m.data
+            elif m.type == MSG_FILTERS:
+                self._filters = self._parse_filters(m.data)
+        if self._dt is None or self._layout is None:
+            raise HDF5Error(f"dataset {name!r}: missing datatype or layout message")
+
+    @property
+    def dtype(self):
+        return self._dt.dtype
+
+    @property
+    def is_reference(self) -> bool:
+        return self._dt.is_ref
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    @staticmethod
+    def _parse_filters(d):
+        version, nf = d[0], d[1]
+        pos = 8 if version == 1 else 2
+        out = []
+        for _ in range(nf):
+            fid = struct.unpack_from("<H", d, pos)[0]
+            if version == 1 or fid >= 256:
+                nlen, fflags, ncd = struct.unpack_from("<HHH", d, pos + 2)
+                pos += 8
+            else:
+                nlen = 0
+                fflags, ncd = struct.unpack_from("<HH", d, pos + 2)
+                pos += 6
+            pos += _pad8(nlen) if version == 1 else nlen
+            cd = struct.unpack_from(f"<{ncd}I", d, pos)
+            pos += 4 * ncd
+            if version == 1 and ncd % 2:
+                pos += 4
+            out.append((fid, fflags, cd))
+        return out
+
+    def _decode_chunk(self, raw: bytes, mask: int) -> bytes:
+        for i in range(len(self._filters) - 1, -1, -1):
+            if mask & (1 << i):
+                continue
+            fid, _, cd = self._filters[i]
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:
+                raw = _unshuffle(raw, cd[0] if cd else self.dtype.itemsize)
+            elif fid == 3:
+                raw = raw[:-4]
+            else:
+                raise HDF5Error(f"dataset {self.name!r}: filter {fid} is not supported")
+        return raw
+
+    def _layout_info(self):
+        d = self._layout
+        version = d[0]
+        if version in (1, 2):
+            ndims, cls = d[1], d[2]
+            pos = 8
+            addr = None
+            if cls != 0:
+                addr = struct.unpack_from("<Q", d, pos)[0]
+                pos += 8
+            dims = struct.unpack_from(f"<{ndims}I", d, pos)
+            pos += 4 * ndims
+            if cls == 0:
+                size = struct.unpack_from("<I", d, pos)[0]
+                return "compact", d[pos + 4: pos + 4 + size], None
+            if cls == 1:
+                return "contiguous", addr, None
+            return "chunked", addr, dims[:-1]
+        if version == 3:
+            cls = d[1]
+            if cls == 0:
+                size = struct.unpack_from("<H", d, 2)[0]
+                return "compact", d[4:4 + size], None
+            if cls == 1:
+                return "contiguous", struct.unpack_from("<Q", d, 2)[0], None
+            if cls == 2:
+                ndims = d[2]
+                addr = struct.unpack_from("<Q", d, 3)[0]
+                dims = struct.unpack_from(f"<{ndims}I", d, 11)
+                return "chunked", addr, dims[:-1]
+        raise HDF5Error(f"dataset {self.name!r}: data layout message version {version} / class {d[1]} "
+                        "is not supported (files written with libver='latest' use version 4)")
+
+    def _chunks(self, addr, ndims, out):
+        f = self.file
+        if addr == UNDEF:
+            return
+        head = f._bytes(addr, 24)
+        if head[:4] != b"TREE" or head[4] != 1:
+            raise HDF5Error(f"bad chunk B-tree node at {addr}")
+        level, used = head[5], struct.unpack_from("<H", head, 6)[0]
+        ksize = 8 + 8 * (ndims + 1)
+        body = f._bytes(addr + 24, used * (ksize + 8) + ksize)
+        for i in range(used):
+            kpos = i * (ksize + 8)
+            csize, cmask = struct.unpack_from("<II", body, kpos)
+            offs = struct.unpack_from(f"<{ndims}Q", body, kpos + 8)
+            child = struct.unpack_from("<Q", body, kpos + ksize)[0]
+            if level > 0:
+                self._chunks(child, ndims, out)
+            else:
+                out.append((offs, csize, cmask, child))
+
+    def read(self, memmap: bool = False) -> np.ndarray:
+        """The whole dataset, in HDF5 dimension order.  ``memmap=True`` returns a read-only view of
+        the file for contiguous data (no copy: use it for the 13 GB sample table)."""
+        kind, where, cdims = self._layout_info()
+        shape, dt = self.shape, self.dtype
+        count = self.size
+        if kind == "compact":
+            return np.frombuffer(where, dtype=dt, count=count).reshape(shape).copy()
+        if kind == "contiguous":
+            if where == UNDEF or count == 0:
+                return np.zeros(shape, dtype=dt)
+            a = np.frombuffer(self.file._mm, dtype=dt, count=count, offset=self.file._abs(where)).reshape(shape)
+            return a if memmap else a.copy()
+        ndims = len(shape)
+        out = np.zeros(shape, dtype=dt)
+        chunks: list = []
+        self._chunks(where, ndims, chunks)
+        for offs, csize, cmask, caddr in chunks:
+            raw = self._decode_chunk(self.file._bytes(caddr, csize), cmask)
+            block = np.frombuffer(raw, dtype=dt, count=int(np.prod(cdims))).reshape(cdims)
+            sel = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, shape))
+            out[sel] = block[tuple(slice(0, s.stop - s.start) for s in sel)]
+        return out
+
+    def __getitem__(self, key):
+        """h5py-style indexing (``ds[()]``, ``ds[0, :]``, ``ds[:, 3]`` ...): the dataset is read and
+        then indexed (contiguous data are only memory-mapped, so slices of large tables are cheap)."""
+        a = self.read(memmap=True)
+        if key == () or key is Ellipsis:
+            return np.array(a)
+        return np.array(a[key])
+
+    def __len__(self):
+        return self.shape[0] if self.shape else 0
+
+
+# =================================================================================================
+# writer
+# =================================================================================================
+
+def _dtype_message(dt: np.dtype, is_ref=False) -> bytes:
+    dt = np.dtype(dt)
+    if is_ref:
+        return struct.pack("<BBBBI", 0x17, 0, 0, 0, 8)
+    if dt.kind == "f" and dt.itemsize in (4, 8):
+        if dt.itemsize == 8:
+            return struct.pack("<BBBBI", 0x11, 0x20, 63, 0, 8) + struct.pack("<HHBBBBI", 0, 64, 52, 11, 0, 52, 1023)
+        return struct.pack("<BBBBI", 0x11, 0x20, 31, 0, 4) + struct.pack("<HHBBBBI", 0, 32, 23, 8, 0, 23, 127)
+    if dt.kind in "iu" and dt.itemsize in (1, 2, 4, 8):
+        bits = 0x08 if dt.kind == "i" else 0
+        return struct.pack("<BBBBI", 0x10, bits, 0, 0, dt.itemsize) + struct.pack("<HH", 0, 8 * dt.itemsize)
+    if dt.kind == "b":
+        return struct.pack("<BBBBI", 0x10, 0, 0, 0, 1) + struct.pack("<HH", 0, 8)
+    if dt.kind == "S":
+        return struct.pack("<BBBBI", 0x13, 0, 0, 0, dt.itemsize)
+    raise HDF5Error(f"cannot store dtype {dt}")
+
+
+def _dataspace_message(shape) -> bytes:
+    shape = tuple(int(s) for s in shape)
+    return struct.pack("<BBBBI", 1, len(shape), 0, 0, 0) + struct.pack(f"<{len(shape)}Q", *shape)
+
+
+def _fill_message(alloc_time: int) -> bytes:
+    """Fill value message, version 2: allocation time (2 late: contiguous, 3 incremental: chunked),
+    written "if set", defined with size 0 = the default (zero) fill value -- what MATLAB's files say."""
+    return struct.pack("<BBBBI", 2, alloc_time, 2, 1, 0)
+
+
+def _message(mtype: int, data: bytes, flags: int = 0) -> bytes:
+    data = data + b"\x00" * (_pad8(len(data)) - len(data))
+    return struct.pack("<HHBBBB", mtype, len(data), flags, 0, 0, 0) + data
+
+
+def _attribute_message(name: str, value) -> bytes:
+    nm = name.encode() + b"\x00"
+    if isinstance(value, (str, bytes)):
+        raw = value.encode() if isinstance(value, str) else value
+        dt = _dtype_message(np.dtype(f"S{max(len(raw), 1)}"))
+        sp = _dataspace_message(())
+        data = raw if raw else b"\x00"
+    else:
+        arr = np.asarray(value)
+        if arr.dtype.kind == "b":
+            arr = arr.astype(np.uint8)
+        if arr.dtype.byteorder == ">":
+            arr = arr.astype(arr.dtype.newbyteorder("<"))
+        dt = _dtype_message(arr.dtype)
+        sp = _dataspace_message(arr.shape)
+        data = np.ascontiguousarray(arr).tobytes()
+
+    def pad(b):
+        return b + b"\x00" * (_pad8(len(b)) - len(b))
+
+    body = struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(sp)) + pad(nm) + pad(dt) + pad(sp) + data
+    return _message(MSG_ATTRIBUTE, body)
+
+
+class Reference:
+    """An object reference to something already written by the same FileWriter."""
+
+    def __init__(self, addr: int):
+        self.addr = int(addr)
+
+
+class FileWriter:
+    """Sequential HDF5 writer.  Objects are appended as they are created; the groups' symbol tables
+    and the superblock are written by :meth:`close`.
+
+    ``userblock``: bytes placed in front of the superblock (MATLAB: the 512-byte text header).  All
+    addresses in the file are relative to the end of the user block, as libhdf5 writes them."""
+
+    GROUP_LEAF_K, GROUP_INTERNAL_K, CHUNK_K = 4, 16, 32  # libhdf5 defaults (superblock version 0)
+
+    def __init__(self, path: str, userblock: bytes = b""):
+        if len(userblock) not in (0,) and (len(userblock) < 512 or len(userblock) & (len(userblock) - 1)):
+            raise HDF5Error("a user block must be a power of two >= 512 bytes long")
+        self.path = str(path)
+        self._f = open(self.path, "wb")
+        self.base = len(userblock)
+        self._f.write(userblock)
+        self._f.write(b"\x00" * 96)  # superblock, patched by close()
+        self._pos = 96               # relative to base
+        self._groups: dict[str, dict[str, int]] = {"/": {}}
+        self._group_attrs: dict[str, dict] = {"/": {}}
+        self._closed = False
+
+    # ---- raw appends ----------------------------------------------------------------------------
+    def _align(self, n: int = 8):
+        pad = (-self._pos) % n
+        if pad:
+            self._f.write(b"\x00" * pad)
+            self._pos += pad
+
+    def _append(self, data: bytes) -> int:
+        self._align(8)
+        addr = self._pos
+        self._f.write(data)
+        self._pos += len(data)
+        return addr
+
+    # ---- groups ---------------------------------------------------------------------------------
+    def create_group(self, name: str, attrs: dict | None = None):
+        name = "/" + name.strip("/")
+        if name in self._groups:
+            raise HDF5Error(f"group {name} exists")
+        parent = name.rsplit("/", 1)[0] or "/"
+        if parent not in self._groups:
+            raise HDF5Error(f"parent group {parent} does not exist")
+        self._groups[name] = {}
+        self._group_attrs[name] = dict(attrs or {})
+
+    def _split(self, name: str):
+        name = "/" + name.strip("/")
+        parent, leaf = name.rsplit("/", 1)
+        parent = parent or "/"
+        if parent not in self._groups:
+            raise HDF5Error(f"group {parent} does not exist (create_group first)")
+        if leaf in self._groups[parent] or name in self._groups:
+            raise HDF5Error(f"{name} exists")
+        return parent, leaf
+
+    # ---- datasets -------------------------------------------------------------------------------
+    def create_dataset_streamed(self, name: str, shape, dtype, blocks, attrs: dict | None = None) -> Reference:
+        """A contiguous dataset of the given ``shape`` written from ``blocks``, an iterable of
+        arrays that are consecutive slabs along axis 0 -- for tables too large to hold a second
+        (transposed) copy of, e.g. the 13 GB ``sample_log_likelihoods_dla`` of a DR12Q run."""
+        parent, leaf = self._split(name)
+        dt = np.dtype(dtype).newbyteorder("<") if np.dtype(dtype).byteorder == ">" else np.dtype(dtype)
+        shape = tuple(int(x) for x in shape)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        self._align(8)
+        daddr, rows = self._pos, 0
+        for blk in blocks:
+            blk = np.ascontiguousarray(blk, dtype=dt)
+            if blk.shape[1:] != shape[1:]:
+                raise HDF5Error(f"block of shape {blk.shape} does not fit dataset shape {shape}")
+            blk.tofile(self._f)
+            rows += blk.shape[0]
+            self._pos += blk.nbytes
+        if rows != shape[0]:
+            raise HDF5Error(f"{name}: blocks delivered {rows} of {shape[0]} slabs")
+        msgs = [_message(MSG_DATASPACE, _dataspace_message(shape)),
+                _message(MSG_DATATYPE, _dtype_message(dt), flags=1),
+                _message(MSG_FILL, _fill_message(2)),
+                _message(MSG_LAYOUT, struct.pack("<BB", 3, 1) + struct.pack("<QQ", daddr if nbytes else UNDEF, nbytes))]
+        for k, v in (attrs or {}).items():
+            msgs.append(_attribute_message(k, v))
+        addr = self._write_object_header(msgs)
+        self._groups[parent][leaf] = addr
+        return Reference(addr)
+
+    def create_dataset(self, name: str, data, attrs: dict | None = None, chunks=None,
+                       compression: str | None = None, shuffle: bool = False) -> Reference:
+        """Write one dataset (dimensions as given: pass MATLAB arrays already transposed).
+        ``data``: array-like, or a list/array of :class:`Reference` for an object-reference
+        dataset.  ``chunks`` + ``compression='gzip'``: chunked layout with the deflate filter (what
+        MATLAB writes); default: contiguous.  Returns a reference to the new dataset."""
+        parent, leaf = self._split(name)
+        is_ref = False
+        if isinstance(data, np.ndarray) and data.dtype == object or (
+                isinstance(data, (list, tuple)) and data and isinstance(data[0], Reference)):
+            flat = np.asarray(data, dtype=object)
+            shape = flat.shape
+            arr = np.array([r.addr for r in flat.reshape(-1)], dtype="<u8").reshape(shape)
+            is_ref = True
+        else:
+            arr = np.asarray(data)
+            if arr.dtype.kind == "b":
+                arr = arr.astype(np.uint8)
+            if arr.dtype.kind == "U":
+                arr = arr.astype("S")
+            if arr.dtype.byteorder == ">":
+                arr = arr.astype(arr.dtype.newbyteorder("<"))
+        arr = np.ascontiguousarray(arr)
+        msgs = [_message(MSG_DATASPACE, _dataspace_message(arr.shape)),
+                _message(MSG_DATATYPE, _dtype_message(arr.dtype, is_ref), flags=1),
+                _message(MSG_FILL, _fill_message(2 if chunks is None else 3))]
+        if chunks is not None:
+            chunks = tuple(int(c) for c in chunks)
+            if len(chunks) != arr.ndim or arr.ndim == 0 or any(c < 1 for c in chunks):
+                raise HDF5Error("chunks must give one positive extent per dimension")
+            filters = []
+            if shuffle:
+                filters.append((2, [arr.dtype.itemsize]))
+            if compression in ("gzip", "deflate"):
+                filters.append((1, [6]))
+            elif compression is not None:
+                raise HDF5Error(f"compression {compression!r} is not supported")
+            btree = self._write_chunks(arr, chunks, filters)
+            if filters:
+                body = struct.pack("<BB6x", 1, len(filters))
+                for fid, cd in filters:
+                    body += struct.pack("<HHHH", fid, 0, 1, len(cd)) + struct.pack(f"<{len(cd)}I", *cd)
+                    if len(cd) % 2:
+                        body += b"\x00" * 4
+                msgs.append(_message(MSG_FILTERS, body, flags=1))
+            layout = struct.pack("<BBB", 3, 2, arr.ndim + 1) + struct.pack("<Q", btree) + struct.pack(
+                f"<{arr.ndim + 1}I", *chunks, arr.dtype.itemsize)
+        else:
+            if arr.size:
+                self._align(8)
+                daddr = self._pos
+                arr.tofile(self._f)
+                self._pos += arr.nbytes
+            else:
+                daddr = UNDEF
+            layout = struct.pack("<BB", 3, 1) + struct.pack("<QQ", daddr, arr.nbytes)
+        msgs.append(_message(MSG_LAYOUT, layout))
+        for k, v in (attrs or {}).items():
+            msgs.append(_attribute_message(k, v))
+        addr = self._write_object_header(msgs)
+        self._groups[parent][leaf] = addr
+        return Reference(addr)
+
+    def _write_object_header(self, msgs) -> int:
+        body = b"".join(msgs)
+        head = struct.pack("<BBHII", 1, 0, len(msgs), 1, len(body)) + b"\x00" * 4
+        return self._append(head + body)
+
+    def _write_chunks(self, arr, chunks, filters) -> int:
+        nd = arr.ndim
+        grid = [range(0, max(s, 1), c) for s, c in zip(arr.shape, chunks)]
+        entries = []  # (offsets, size, address)
+        for idx in np.ndindex(*[len(g) for g in grid]):
+            offs = tuple(g[i] for g, i in zip(grid, idx))
+            block = np.zeros(chunks, dtype=arr.dtype)
+            sel = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunks, arr.shape))
+            block[tuple(slice(0, s.stop - s.start) for s in sel)] = arr[sel]
+            raw = block.tobytes()
+            for fid, cd in filters:
+                raw = _shuffle(raw, cd[0]) if fid == 2 else zlib.compress(raw, cd[0])
+            entries.append((offs, len(raw), self._append(raw)))
+        if not entries:
+            return UNDEF
+        ksize = 8 + 8 * (nd + 1)
+        cap = 2 * self.CHUNK_K
+        node_bytes = 24 + (cap + 1) * ksize + cap * 8
+
+        def key(offs, size):
+            return struct.pack("<II", size, 0) + struct.pack(f"<{nd + 1}Q", *offs, 0)
+
+        level = 0
+        nodes = entries  # at level 0: children are chunks
+        while True:
+            groups = [nodes[i:i + cap] for i in range(0, len(nodes), cap)]
+            addrs = []
+            start = self._pos + ((-self._pos) % 8)
+            for gi, g in enumerate(groups):
+                left = start + (gi - 1) * node_bytes if gi > 0 else UNDEF
+                right = start + (gi + 1) * node_bytes if gi + 1 < len(groups) else UNDEF
+                buf = b"TREE" + struct.pack("<BBHQQ", 1, level, len(g), left, right)
+                for offs, size, child in g:
+                    buf += key(offs, size) + struct.pack("<Q", child)
+                last = tuple(o + c for o, c in zip(g[-1][0], chunks))  # beyond every chunk of the node
+                buf += key(last, 0)
+                buf += b"\x00" * (node_bytes - len(buf))
+                addrs.append(self._append(buf))
+            assert addrs[0] == start
+            if len(groups) == 1:
+                return addrs[0]
+            nodes = [(g[0][0], g[0][1], a) for g, a in zip(groups, addrs)]
+            level += 1
+
+    # ---- close: groups + superblock -------------------------------------------------------------
+    def _write_group(self, path: str) -> tuple[int, int, int]:
+        """Heap + SNODs + B-tree + object header of one group (children first).  Returns
+        (object header address, B-tree address, heap address)."""
+        links = dict(self._groups[path])
+        prefix = path.rstrip("/") + "/"
+        for sub in [g for g in self._groups if g != path and g.startswith(prefix) and "/" not in g[len(prefix):]]:
+            links[sub[len(prefix):]] = self._write_group(sub)[0]
+        names = sorted(links, key=lambda s: s.encode())  # strcmp order
+        # local heap: "" at offset 0, then the names, 8-byte aligned, then one free block
+        heap = bytearray(8)
+        offsets = {}
+        for n in names:
+            offsets[n] = len(heap)
+            b = n.encode() + b"\x00"
+            heap += b + b"\x00" * (_pad8(len(b)) - len(b))
+        free_off = len(heap)
+        heap += struct.pack("<QQ", 1, 16)  # a last free block of 16 bytes: next = H5HL_FREE_NULL (1)
+        data_addr = self._append(bytes(heap))
+        heap_addr = self._append(b"HEAP" + struct.pack("<BBBBQQQ", 0, 0, 0, 0, len(heap), free_off, data_addr))
+        # symbol table nodes
+        per = 2 * self.GROUP_LEAF_K
+        snods = []  # (last name, address)
+        for i in range(0, len(names), per):
+            part = names[i:i + per]
+            buf = b"SNOD" + struct.pack("<BBH", 1, 0, len(part))
+            for n in part:
+                buf += struct.pack("<QQII16x", offsets[n], links[n], 0, 0)
+            buf += b"\x00" * (8 + per * 40 - len(buf))
+            snods.append((part[-1], self._append(buf)))
+        # B-tree (type 0), bottom-up
+        cap = 2 * self.GROUP_INTERNAL_K
+        node_bytes = 24 + (2 * cap + 1) * 8
+        level, nodes = 0, snods
+        if not nodes:
+            buf = b"TREE" + struct.pack("<BBHQQ", 0, 0, 0, UNDEF, UNDEF) + struct.pack("<Q", 0)
+            btree = self._append(buf + b"\x00" * (node_bytes - len(buf)))
+        while nodes:
+            groups = [nodes[i:i + cap] for i in range(0, len(nodes), cap)]
+            start = self._pos + ((-self._pos) % 8)
+            addrs = []
+            prev_last = None
+            for gi, g in enumerate(groups):
+                left = start + (gi - 1) * node_bytes if gi > 0 else UNDEF
+                right = start + (gi + 1) * node_bytes if gi + 1 < len(groups) else UNDEF
+                buf = b"TREE" + struct.pack("<BBHQQ", 0, level, len(g), left, right)
+                buf += struct.pack("<Q", offsets[prev_last] if prev_last is not None else 0)
+                for last, child in g:
+                    buf += struct.pack("<QQ", child, offsets[last])
+                prev_last = g[-1][0]
+                buf += b"\x00" * (node_bytes - len(buf))
+                addrs.append(self._append(buf))
+            if len(groups) == 1:
+                btree = addrs[0]
+                break
+            nodes = [(g[-1][0], a) for g, a in zip(groups, addrs)]
+            level += 1
+        msgs = [_message(MSG_SYMBOL_TABLE, struct.pack("<QQ", btree, heap_addr))]
+        for k, v in self._group_attrs[path].items():
+            msgs.append(_attribute_message(k, v))
+        return self._write_object_header(msgs), btree, heap_addr
+
+    def close(self):
+        if self._closed:
+            return
+        root, btree, heap = self._write_group("/")
+        self._align(8)
+        eof_abs = self.base + self._pos
+        sb = SIGNATURE + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, self.GROUP_LEAF_K,
+                                     self.GROUP_INTERNAL_K, 0)
+        sb += struct.pack("<QQQQ", self.base, UNDEF, eof_abs, UNDEF)
+        sb += struct.pack("<QQII", 0, root, 1, 0) + struct.pack("<QQ", btree, heap)
+        assert len(sb) == 96
+        self._f.seek(self.base)
+        self._f.write(sb)
+        self._f.close()
+        self._closed = True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        if exc_type is None:
+            self.close()
+        else:
+            self._f.close()

@@ -1,48 +1,181 @@
 """Readers/writers for the .mat files either side of the hot path.
 
-The reference hands data between stages through MATLAB files: ``learned_qso_model_*.mat``
-(learn_qso_model.m:113-123), ``dla_samples.mat`` (generate_dla_samples.m:59-63),
-``preloaded_qsos.mat`` (preload_qsos.m:64-79), ``catalog.mat`` (build_catalogs.m:86-91) and the
-output ``processed_qsos_*.mat`` (process_qsos.m:236-250).  They are saved with ``-v7.3`` (HDF5).
+The reference hands data between stages through MATLAB files saved with ``-v7.3``, i.e. HDF5
+behind a 512-byte MATLAB header: ``learned_qso_model_*.mat`` (learn_qso_model.m:113-123),
+``dla_samples.mat`` (generate_dla_samples.m:59-63), ``preloaded_qsos.mat`` (preload_qsos.m:64-79),
+``catalog.mat`` (build_catalogs.m:86-91) and the outputs ``processed_qsos_*.mat``
+(process_qsos.m:236-250; multi_dlas/process_qsos_multiple_dlas_meanflux.m:498-523), which
+``CDDF_analysis`` then opens with ``h5py.File`` and indexes as ``f['p_dlas'][0, :]``,
+``f['model_posteriors'][()].T``, ``f['test_ind'][0, :]`` (qso_loader.py:84-112, calc_cddf.py:104).
 
-* v7.3 files need ``h5py`` (not installed in the build image; imported lazily).  HDF5 stores MATLAB
-  arrays transposed, and cell arrays as object references; both are undone here so callers see the
-  MATLAB shapes.
-* v5/v7 files (``save -v7``) go through ``scipy.io``; this is also what the tests use.
-* Output is written as a v5 ``.mat`` with exactly the variable names the reference saves, arrays
-  in MATLAB orientation (``sample_log_likelihoods_dla`` is [num_quasars x S]), so
-  ``CDDF_analysis/qso_loader.py``-style consumers only need their usual ``.T`` when they read it
-  through h5py-free paths.
+* ``-v7.3`` files are read and written with the package's own minimal HDF5 implementation
+  (:mod:`.hdf5`): neither h5py nor libhdf5 exists in the build image or on the GPU box.  MATLAB's
+  conventions are applied on top of it here: arrays are stored with their dimensions reversed
+  (column-major data in a row-major container), logicals as uint8 and chars as uint16 with the
+  ``MATLAB_class`` / ``MATLAB_int_decode`` attributes, cell arrays as object references into the
+  ``#refs#`` group, empty arrays through ``MATLAB_empty``.
+* v5/v7 files (``save -v7``) go through ``scipy.io``.
+
+All functions here speak MATLAB orientation (``sample_log_likelihoods_dla`` is [num_quasars x S],
+multi-DLA: [num_quasars x S x max_dlas]) unless stated otherwise.
 """
 from __future__ import annotations
 
+import datetime
+
 import numpy as np
+
+from . import hdf5
+
+MATLAB_HEADER_TEXT = "MATLAB 7.3 MAT-file, Platform: GLNXA64, Created on: {date} HDF5 schema 1.00 ."
 
 
 def _is_hdf5(path: str) -> bool:
     with open(path, "rb") as f:
-        head = f.read(128)
-    return b"MATLAB 7.3" in head or head[:8] == b"\x89HDF\r\n\x1a\n"
+        head = f.read(520)
+    return b"MATLAB 7.3" in head[:128] or head[:8] == hdf5.SIGNATURE or head[512:520] == hdf5.SIGNATURE
+
+
+# ---------------------------------------------------------------------------------------------
+# -v7.3 <-> NumPy, MATLAB conventions
+# ---------------------------------------------------------------------------------------------
+
+def matlab_userblock(created: str | None = None) -> bytes:
+    """The 512-byte block MATLAB puts in front of the HDF5 superblock: 116 bytes of text, 8 bytes
+    of subsystem offset, version 0x0200 and the endian indicator 'IM'; zero-filled to 512."""
+    date = created or datetime.datetime.now().strftime("%a %b %d %H:%M:%S %Y")
+    text = MATLAB_HEADER_TEXT.format(date=date).encode("ascii")[:116].ljust(116, b" ")
+    return (text + b"\x00" * 8 + b"\x00\x02" + b"IM").ljust(512, b"\x00")
+
+
+def _from_dataset(f: hdf5.File, ds, deref_depth: int = 2):
+    """One HDF5 object of a -v7.3 file as MATLAB holds it."""
+    if isinstance(ds, hdf5.Group):  # struct: fields are the group's members
+        return {k: _from_dataset(f, ds[k], deref_depth) for k in ds.keys()}
+    cls = ds.attrs.get("MATLAB_class", "")
+    if "MATLAB_empty" in ds.attrs:
+        dims = tuple(int(x) for x in ds.read().ravel())
+        return [] if cls == "cell" else np.zeros(dims, dtype=bool if cls == "logical" else np.float64)
+    a = ds.read()
+    if ds.is_reference:
+        if deref_depth <= 0:
+            return a.T
+        flat = [_from_dataset(f, f.dereference(r), deref_depth - 1) for r in a.T.ravel(order="F")]
+        return flat  # cell arrays come back as flat lists in MATLAB's (column-major) element order
+    a = a.T  # undo the dimension reversal
+    if cls == "logical":
+        return a.astype(bool)
+    if cls == "char":
+        return "".join(chr(c) for c in a.ravel(order="F"))
+    return a
+
+
+def loadmat73(path: str, names=None) -> dict:
+    """Variables of a ``-v7.3`` file in MATLAB orientation ({name: array | str | list (cell) |
+    dict (struct)}).  ``names``: the variables wanted (default: all but ``#refs#``)."""
+    out = {}
+    with hdf5.File(path) as f:
+        for n in (names if names is not None else [k for k in f.keys() if not k.startswith("#")]):
+            if n in f:
+                out[n] = _from_dataset(f, f[n])
+    return out
+
+
+class _MatWriter:
+    """savemat for ``-v7.3``: values in MATLAB orientation."""
+
+    def __init__(self, path: str, created: str | None = None):
+        self.w = hdf5.FileWriter(path, userblock=matlab_userblock(created))
+        self._refs = 0
+
+    @staticmethod
+    def _class_of(a: np.ndarray) -> str:
+        if a.dtype.kind == "b":
+            return "logical"
+        if a.dtype.kind == "f":
+            return "double" if a.dtype.itemsize == 8 else "single"
+        return {"i": "int", "u": "uint"}[a.dtype.kind] + str(8 * a.dtype.itemsize)
+
+    def _array(self, name: str, value, compress: bool):
+        a = np.asarray(value)
+        if a.dtype.kind == "O":
+            raise TypeError(f"{name}: object arrays are written as cells; pass a list")
+        if a.ndim < 2:  # MATLAB has no 0-d / 1-d arrays: scalars are 1x1, vectors columns
+            a = a.reshape(-1, 1) if a.ndim == 1 else a.reshape(1, 1)
+        attrs = {"MATLAB_class": self._class_of(a)}
+        if a.dtype.kind == "b":
+            attrs["MATLAB_int_decode"] = np.int32(1)
+        if a.size == 0:
+            attrs["MATLAB_empty"] = np.int32(1)
+            return self.w.create_dataset(name, np.array(a.shape, dtype=np.uint64), attrs=attrs)
+        data = np.ascontiguousarray(a.T)  # dimensions reversed, as MATLAB stores them
+        if compress and data.nbytes >= 4096:
+            chunks = list(data.shape)
+            while int(np.prod(chunks)) * data.dtype.itemsize > (1 << 20):  # ~1 MiB chunks, as MATLAB
+                ax = int(np.argmax(chunks))
+                chunks[ax] = (chunks[ax] + 1) // 2
+            return self.w.create_dataset(name, data, attrs=attrs, chunks=chunks, compression="gzip")
+        return self.w.create_dataset(name, data, attrs=attrs)
+
+    def _string(self, name: str, value: str):
+        codes = np.array([ord(c) for c in value], dtype=np.uint16).reshape(-1, 1)  # 1 x len, reversed
+        attrs = {"MATLAB_class": "char", "MATLAB_int_decode": np.int32(2)}
+        if codes.size == 0:
+            attrs["MATLAB_empty"] = np.int32(1)
+            return self.w.create_dataset(name, np.array([0, 0], dtype=np.uint64), attrs=attrs)
+        return self.w.create_dataset(name, codes, attrs=attrs)
+
+    def _cell(self, name: str, items, compress: bool):
+        if "/#refs#" not in self.w._groups:
+            self.w.create_group("#refs#")
+        refs = []
+        for it in items:
+            self._refs += 1
+            refs.append(self.put(f"#refs#/{self._refs:08d}", it, compress))
+        if not refs:
+            return self.w.create_dataset(name, np.array([0, 0], dtype=np.uint64),
+                                         attrs={"MATLAB_class": "cell", "MATLAB_empty": np.int32(1)})
+        arr = np.empty((1, len(refs)), dtype=object)  # an N x 1 cell, dimensions reversed
+        arr[0, :] = refs
+        return self.w.create_dataset(name, arr, attrs={"MATLAB_class": "cell"})
+
+    def put(self, name: str, value, compress: bool = False):
+        if isinstance(value, str):
+            return self._string(name, value)
+        if isinstance(value, (list, tuple)):
+            return self._cell(name, value, compress)
+        return self._array(name, value, compress)
+
+    def put_streamed(self, name: str, matlab_shape, dtype, column_blocks):
+        """A MATLAB array too large to transpose in memory.  ``column_blocks`` yields consecutive
+        slabs of the STORED (dimension-reversed) array along its first axis -- i.e. slabs along the
+        LAST MATLAB dimension, each already reversed."""
+        a = np.dtype(dtype)
+        cls = "double" if a.kind == "f" and a.itemsize == 8 else self._class_of(np.zeros(0, a))
+        return self.w.create_dataset_streamed(name, tuple(matlab_shape)[::-1], a, column_blocks,
+                                              attrs={"MATLAB_class": cls})
+
+    def close(self):
+        self.w.close()
+
+
+def savemat73(path: str, variables: dict, compress: bool = False, created: str | None = None) -> None:
+    """``save(path, ..., '-v7.3')`` for a dict of variables in MATLAB orientation: arrays, scalars,
+    strings, and lists (written as N x 1 cell arrays).  ``compress``: chunked + deflate datasets
+    like MATLAB's own files (default: contiguous, which every HDF5 reader takes and which can be
+    memory-mapped)."""
+    w = _MatWriter(path, created)
+    try:
+        for k, v in variables.items():
+            w.put(k, v, compress)
+    finally:
+        w.close()
 
 
 def _load_mat(path: str, names):
-    """Returns {name: array} in MATLAB orientation for the requested variables."""
+    """{name: array} in MATLAB orientation for the requested variables (cells -> lists)."""
     if _is_hdf5(path):
-        try:
-            import h5py
-        except ImportError as e:  # pragma: no cover - h5py is absent from the build image
-            raise ImportError(f"{path} is a -v7.3 (HDF5) .mat file; reading it needs h5py") from e
-        out = {}
-        with h5py.File(path, "r") as f:
-            for n in names:
-                if n not in f:
-                    continue
-                d = f[n]
-                if d.dtype == object:  # cell array: one reference per element
-                    out[n] = [np.array(f[r]).T.squeeze() for r in np.array(d).ravel()]
-                else:
-                    out[n] = np.array(d).T
-        return out
+        return loadmat73(path, names)
     from scipy.io import loadmat
     raw = loadmat(path, variable_names=list(names), squeeze_me=False)
     out = {}
@@ -50,16 +183,17 @@ def _load_mat(path: str, names):
         if n not in raw:
             continue
         v = raw[n]
-        if v.dtype == object:
-            out[n] = [np.asarray(c).squeeze() for c in v.ravel()]
-        else:
-            out[n] = v
+        out[n] = [np.asarray(c).squeeze() for c in v.ravel()] if v.dtype == object else v
     return out
 
 
 def _vec(a):
     return np.asarray(a, dtype=np.float64).reshape(-1)
 
+
+# ---------------------------------------------------------------------------------------------
+# inputs of the path
+# ---------------------------------------------------------------------------------------------
 
 def load_learned_model(path: str) -> dict:
     """Variables of process_qsos.m:30-35."""
@@ -88,38 +222,148 @@ def load_dla_samples(path: str) -> dict:
     return out
 
 
+def load_catalog(path: str, names=("z_qsos", "thing_ids", "plates", "mjds", "fiber_ids", "snrs",
+                                   "filter_flags", "los_inds", "dla_inds")) -> dict:
+    """catalog.mat (build_catalogs.m:86-91): the per-quasar columns as flat vectors.  ``los_inds`` /
+    ``dla_inds`` are containers.Map objects in the reference's file, which HDF5 stores opaquely; they
+    are returned only when they are plain arrays."""
+    m = _load_mat(path, names)
+    return {k: (np.asarray(v).reshape(-1) if isinstance(v, np.ndarray) else v) for k, v in m.items()}
+
+
 def load_preloaded_qsos(path: str, z_qsos, test_ind=None) -> list:
     """The ragged cell arrays of preload_qsos.m:64-79 as a list of per-quasar dicts, after the
-    ``test_ind`` subset of process_qsos.m:56-61 (boolean mask or index array, 0-based)."""
-    m = _load_mat(path, ("all_wavelengths", "all_flux", "all_noise_variance", "all_pixel_mask"))
-    n = len(m["all_wavelengths"])
+    ``test_ind`` subset of process_qsos.m:56-61 (boolean mask or index array, 0-based).  In a
+    -v7.3 file only the selected cells are dereferenced."""
+    keys = ("all_wavelengths", "all_flux", "all_noise_variance", "all_pixel_mask")
     z = _vec(z_qsos)
-    if z.size != n:
-        raise ValueError(f"{n} spectra but {z.size} redshifts")
-    idx = np.arange(n) if test_ind is None else np.flatnonzero(test_ind) if np.asarray(test_ind).dtype == bool \
-        else np.asarray(test_ind)
-    return [dict(wavelengths=_vec(m["all_wavelengths"][i]), flux=_vec(m["all_flux"][i]),
-                 noise_variance=_vec(m["all_noise_variance"][i]),
-                 pixel_mask=np.asarray(m["all_pixel_mask"][i]).reshape(-1).astype(np.uint8),
-                 z_qso=float(z[i])) for i in idx]
+
+    def pick(n):
+        if n != z.size:
+            raise ValueError(f"{n} spectra but {z.size} redshifts")
+        if test_ind is None:
+            return np.arange(n)
+        t = np.asarray(test_ind)
+        return np.flatnonzero(t) if t.dtype == bool else t
+
+    if _is_hdf5(path):
+        with hdf5.File(path) as f:
+            refs = {}
+            for k in keys:
+                if k not in f:
+                    raise KeyError(f"{path} lacks {k}")
+                refs[k] = f[k].read().T.ravel(order="F")
+            idx = pick(refs[keys[0]].size)
+            cells = {k: [_from_dataset(f, f.dereference(refs[k][i])) for i in idx] for k in keys}
+    else:
+        m = _load_mat(path, keys)
+        idx = pick(len(m["all_wavelengths"]))
+        cells = {k: [m[k][i] for i in idx] for k in keys}
+    return [dict(wavelengths=_vec(cells["all_wavelengths"][j]), flux=_vec(cells["all_flux"][j]),
+                 noise_variance=_vec(cells["all_noise_variance"][j]),
+                 pixel_mask=np.asarray(cells["all_pixel_mask"][j]).reshape(-1).astype(np.uint8),
+                 z_qso=float(z[i])) for j, i in enumerate(idx)]
 
 
-#: process_qsos.m:236-244
+# ---------------------------------------------------------------------------------------------
+# outputs of the path
+# ---------------------------------------------------------------------------------------------
+
+#: process_qsos.m:236-244 (result variables; the run metadata of :236-238 are keyword arguments)
 SAVED_VARIABLES = ("min_z_dlas", "max_z_dlas", "log_priors_no_dla", "log_priors_dla",
                    "log_likelihoods_no_dla", "sample_log_likelihoods_dla", "log_likelihoods_dla",
                    "log_posteriors_no_dla", "log_posteriors_dla", "model_posteriors", "p_no_dlas",
                    "p_dlas")
 
+#: multi_dlas/process_qsos_multiple_dlas_meanflux.m:498-510
+SAVED_VARIABLES_MULTI = ("min_z_dlas", "max_z_dlas", "sample_log_likelihoods_dla", "base_sample_inds",
+                         "log_priors_no_dla", "log_priors_dla", "log_priors_lls",
+                         "log_likelihoods_no_dla", "MAP_z_dlas", "MAP_log_nhis", "log_likelihoods_dla",
+                         "log_likelihoods_lls", "log_posteriors_no_dla", "log_posteriors_dla",
+                         "log_posteriors_lls", "model_posteriors", "p_no_dlas", "p_dlas", "p_lls",
+                         "all_exceptions", "sample_log_likelihoods_lls")
 
-def save_processed_qsos(path: str, results: dict, **run_metadata) -> None:
-    """process_qsos.m:236-250: the result variables (column vectors / [nq x S] matrices as MATLAB
-    holds them) plus the run metadata the script echoes (training_release, test_set_name, ...)."""
-    from scipy.io import savemat
-    out = dict(run_metadata)
-    for k in ("prior_z_qso_increase", "max_z_cut", "num_lines"):
-        if k in results:
-            out[k] = results[k]
-    for k in SAVED_VARIABLES:
-        v = np.asarray(results[k], dtype=np.float64)
-        out[k] = v.reshape(-1, 1) if v.ndim == 1 else v
-    savemat(path, out, do_compression=True)
+#: how this package's multi-DLA arrays ([nq, model, S] etc.) map onto MATLAB's axes (multi :110-131)
+_MULTI_TO_MATLAB = {"sample_log_likelihoods_dla": (0, 2, 1),   # [nq, md, S] -> [nq, S, md]
+                    "base_sample_inds": (0, 2, 1)}              # [nq, md-1, S] -> [nq, S, md-1]
+
+
+def _metadata(w: _MatWriter, results: dict, run_metadata: dict, extra=()):
+    for k, v in run_metadata.items():
+        w.put(k, v)
+    for k in ("prior_z_qso_increase", "max_z_cut", "num_lines") + tuple(extra):
+        if k in results and k not in run_metadata:
+            w.put(k, np.float64(results[k]))
+
+
+def _streamed_table(w: _MatWriter, name: str, table: np.ndarray, block_rows: int = 64):
+    """[nq, S] -> the MATLAB variable [nq x S], i.e. a stored (S, nq) array, written in slabs of
+    ``block_rows`` samples so that the 13 GB table of a DR12Q run is never duplicated."""
+    nq, S = table.shape
+    w.put_streamed(name, (nq, S), np.float64,
+                   (np.ascontiguousarray(table[:, i:i + block_rows].T) for i in range(0, S, block_rows)))
+
+
+def save_processed_qsos(path: str, results: dict, test_ind=None, **run_metadata) -> None:
+    """process_qsos.m:236-250 as a ``-v7.3`` file ``CDDF_analysis`` reads unchanged: the result
+    variables (column vectors, ``sample_log_likelihoods_dla`` [nq x S], ``model_posteriors``
+    [nq x 2]), ``test_ind`` (logical column, read back as ``f['test_ind'][0, :]``,
+    qso_loader.py:95) and the run metadata the script echoes (training_release, training_set_name,
+    dla_catalog_name, prior_ind, release, test_set_name, ...)."""
+    w = _MatWriter(path)
+    try:
+        _metadata(w, results, run_metadata)
+        if test_ind is not None:
+            w.put("test_ind", np.asarray(test_ind, dtype=bool).reshape(-1, 1))
+        for k in SAVED_VARIABLES:
+            v = np.asarray(results[k], dtype=np.float64)
+            if k == "sample_log_likelihoods_dla" and v.nbytes > (256 << 20):
+                _streamed_table(w, k, v)
+            else:
+                w.put(k, v)
+        for k in ("MAP_inds", "MAP_z_dlas", "MAP_log_nhis"):  # generate_ascii_catalog.m:73-80 (extra)
+            if k in results and np.ndim(results[k]) == 1:
+                w.put(k, np.asarray(results[k], dtype=np.float64))
+    finally:
+        w.close()
+
+
+def save_processed_qsos_multi(path: str, results: dict, test_ind=None, **run_metadata) -> None:
+    """multi_dlas/process_qsos_multiple_dlas_meanflux.m:498-523 as a ``-v7.3`` file:
+    ``sample_log_likelihoods_dla`` [nq x S x max_dlas] (read back as ``[max_dlas, S, nq]``,
+    calc_cddf.py:266), ``base_sample_inds`` uint32 [nq x S x max_dlas-1] (:116), ``MAP_*``
+    [nq x model x slot] (:129-131; ``f['MAP_log_nhis'][()].T``, qso_loader.py:107-109),
+    ``model_posteriors`` [nq x 2+max_dlas], ``all_exceptions`` (:139)."""
+    w = _MatWriter(path)
+    try:
+        _metadata(w, results, run_metadata, extra=("k", "min_z_cut", "num_dla_samples",
+                                                   "normalization_min_lambda", "normalization_max_lambda"))
+        if test_ind is not None:
+            w.put("test_ind", np.asarray(test_ind, dtype=bool).reshape(-1, 1))
+        for k in SAVED_VARIABLES_MULTI + ("MAP_inds",):
+            if k not in results:
+                if k == "MAP_inds":
+                    continue
+                raise KeyError(f"results lack {k}")
+            v = np.asarray(results[k])
+            if k in _MULTI_TO_MATLAB:
+                v = np.transpose(v, _MULTI_TO_MATLAB[k])
+            w.put(k, v.astype(np.uint32) if k == "base_sample_inds" else v.astype(np.float64))
+    finally:
+        w.close()
+
+
+def load_processed_qsos(path: str) -> dict:
+    """A processed_qsos_*.mat written by the reference or by this package, in this package's
+    orientation (vectors flat; multi-DLA 3-D arrays as [nq, model, S] / [nq, model, slot])."""
+    m = loadmat73(path) if _is_hdf5(path) else _load_mat(path, SAVED_VARIABLES_MULTI + SAVED_VARIABLES
+                                                        + ("test_ind", "MAP_inds"))
+    out = {}
+    for k, v in m.items():
+        if isinstance(v, np.ndarray):
+            if v.ndim == 2 and 1 in v.shape and k not in ("model_posteriors",):
+                v = v.reshape(-1)
+            elif v.ndim == 3 and k in _MULTI_TO_MATLAB:
+                v = np.transpose(v, (0, 2, 1))
+        out[k] = v
+    return out

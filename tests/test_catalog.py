@@ -38,3 +38,41 @@ def test_ascii_formats(tmp_path):
     assert f[5] == "-1.50025e+03" and f[7] == "2.50000e-001" and f[8] == "7.50000e-001"
     assert lines[1].split()[7] == "1.00000e-012"  # three-digit exponent (:68-71)
     assert len(lines) == 3
+
+
+def test_json_catalogues(tmp_path):
+    """qso_loader.py:1927-2087 on a hand-made multi-DLA result table: model order (no DLA, sub-DLA,
+    1..max_dlas DLAs); with sub_dla the sub-DLA mass counts as "no DLA"."""
+    import json
+    md = 3
+    mp = np.array([[0.7, 0.2, 0.1, 0.0, 0.0],     # no DLA
+                   [0.1, 0.6, 0.2, 0.1, 0.0],     # sub-DLA most probable -> num_dlas 0
+                   [0.05, 0.05, 0.2, 0.6, 0.1],   # two DLAs
+                   [0.0, 0.1, 0.8, 0.1, 0.0]])    # one DLA
+    nq = mp.shape[0]
+    map_z = np.full((nq, md, md), np.nan)
+    map_n = np.full((nq, md, md), np.nan)
+    map_z[2, 1, :2], map_n[2, 1, :2] = [2.5, 2.9], [20.5, 21.25]
+    map_z[3, 0, :1], map_n[3, 0, :1] = [3.1], [20.9]
+    res = dict(model_posteriors=mp, p_dlas=1 - mp[:, 0] - mp[:, 1], p_no_dlas=mp[:, 0].copy(),
+               min_z_dlas=np.full(nq, 2.0), max_z_dlas=np.full(nq, 3.5), MAP_z_dlas=map_z, MAP_log_nhis=map_n)
+    info = dict(ras=np.arange(nq) * 1.5, decs=-np.arange(nq) * 0.5, plates=np.arange(3586, 3586 + nq),
+                mjds=np.full(nq, 55181), fiber_ids=np.arange(16, 16 + nq), thing_ids=np.arange(1000, 1000 + nq),
+                z_qsos=np.full(nq, 3.6), snrs=np.linspace(1, 4, nq))
+    cat = catalog.generate_json_catalogue(res, info, tmp_path / "predictions_multi_DLAs.json")
+    assert [c["num_dlas"] for c in cat] == [0, 0, 2, 1]
+    assert cat[0]["p_no_dla"] == 0.7 + 0.2 and cat[0]["max_model_posterior"] == cat[0]["p_no_dla"]
+    assert cat[1]["max_model_posterior"] == cat[1]["p_no_dla"] == 0.1 + 0.6
+    assert cat[2]["max_model_posterior"] == 0.6
+    assert cat[2]["dlas"] == [{"log_nhi": 20.5, "z_dla": 2.5}, {"log_nhi": 21.25, "z_dla": 2.9}]
+    assert cat[3]["dlas"] == [{"log_nhi": 20.9, "z_dla": 3.1}] and cat[0]["dlas"] == []
+    assert set(cat[0]) == {"p_dla", "p_no_dla", "max_model_posterior", "num_dlas", "dlas", "min_z_dla",
+                           "max_z_dla", "ra", "snr", "dec", "plate", "mjd", "fiber_id", "thing_id", "z_qso"}
+    back = json.load(open(tmp_path / "predictions_multi_DLAs.json"))
+    assert back == cat and isinstance(back[2]["plate"], int)
+    sub = catalog.generate_sub_dla_catalogue(res, info, tmp_path / "sub.json")
+    assert len(sub) == 1 and sub[0]["p_sub_dla"] == 0.6 and sub[0]["thing_id"] == 1001
+    assert set(sub[0]) == {"p_sub_dla", "ra", "snr", "dec", "plate", "mjd", "fiber_id", "thing_id", "z_qso"}
+    # without the sub-DLA model the model index IS the number of absorbers minus... (:1973 only)
+    plain = catalog.generate_json_catalogue(res, info, sub_dla=False)
+    assert plain[0]["p_no_dla"] == 0.7 and [c["num_dlas"] for c in plain] == [0, 1, 3, 2]

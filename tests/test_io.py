@@ -1,4 +1,5 @@
-"""Round trips of the .mat readers/writers through scipy (v5 files; -v7.3 needs h5py)."""
+"""Round trips of the .mat readers/writers: v5 files through scipy, -v7.3 (HDF5) files through the
+package's own HDF5 implementation (tests/test_hdf5.py tests that layer by itself)."""
 import numpy as np
 import pytest
 from scipy.io import loadmat, savemat
@@ -39,22 +40,105 @@ def test_preloaded_cells_and_output(tmp_path):
     np.testing.assert_array_equal(got[1]["wavelengths"], spectra[2]["wavelengths"])
     np.testing.assert_array_equal(got[2]["pixel_mask"], spectra[3]["pixel_mask"])
     assert np.array_equal(np.isnan(got[0]["flux"]), np.isnan(spectra[0]["flux"]))
-    res = {k: np.arange(3.0) for k in io.SAVED_VARIABLES}
-    res["sample_log_likelihoods_dla"] = np.arange(15.0).reshape(3, 5)
-    res["model_posteriors"] = np.ones((3, 2)) / 2
-    res["num_lines"] = 3
-    io.save_processed_qsos(str(tmp_path / "o.mat"), res, test_set_name="dr12q")
-    back = loadmat(tmp_path / "o.mat")
-    assert back["sample_log_likelihoods_dla"].shape == (3, 5) and back["p_dlas"].shape == (3, 1)
-    assert back["test_set_name"][0] == "dr12q" and int(back["num_lines"].ravel()[0]) == 3
 
 
-def test_v73_needs_h5py(tmp_path):
-    p = tmp_path / "v73.mat"
-    p.write_bytes(b"MATLAB 7.3 MAT-file, Platform: GLNXA64" + b" " * 90 + b"\x89HDF\r\n\x1a\n")
-    try:
-        import h5py  # noqa: F401
-        pytest.skip("h5py present")
-    except ImportError:
-        with pytest.raises(ImportError):
-            io.load_dla_samples(str(p))
+def cells_of(spectra):
+    out = {}
+    for key, src in (("all_wavelengths", "wavelengths"), ("all_flux", "flux"),
+                     ("all_noise_variance", "noise_variance"), ("all_pixel_mask", "pixel_mask")):
+        out[key] = [np.asarray(sp[src]).astype(bool if src == "pixel_mask" else np.float64).reshape(-1, 1)
+                    for sp in spectra]
+    return out
+
+
+def test_v73_inputs_round_trip(tmp_path):
+    """The three input files of process_qsos.m:30-49 as -v7.3 (HDF5) files, as the reference
+    saves them: model, samples (row vectors), preloaded ragged cells incl. logical masks."""
+    model = synthetic.make_model(20)
+    io.savemat73(str(tmp_path / "m.mat"), {k: (np.asarray(v).reshape(-1, 1) if np.ndim(v) == 1 else v)
+                                           for k, v in model.items()}, compress=True)
+    got = io.load_learned_model(str(tmp_path / "m.mat"))
+    for k in ("rest_wavelengths", "mu", "log_omega", "M"):
+        np.testing.assert_array_equal(got[k], model[k])
+    assert got["log_tau_0"] == model["log_tau_0"]
+    s = synthetic.make_samples(64)
+    io.savemat73(str(tmp_path / "s.mat"), {k: v.reshape(1, -1) for k, v in s.items()})
+    gs = io.load_dla_samples(str(tmp_path / "s.mat"))
+    for k in ("offset_samples", "log_nhi_samples", "nhi_samples", "lls_nhi_samples"):
+        np.testing.assert_array_equal(gs[k], s[k])
+    spectra = [synthetic.make_spectrum(i, 50 + 7 * i, model, mask_fraction=0.1) for i in range(5)]
+    io.savemat73(str(tmp_path / "p.mat"), cells_of(spectra), compress=True)
+    z = [sp["z_qso"] for sp in spectra]
+    got = io.load_preloaded_qsos(str(tmp_path / "p.mat"), z, test_ind=np.array([True, False, True, True, False]))
+    assert len(got) == 3 and got[1]["z_qso"] == z[2]
+    np.testing.assert_array_equal(got[1]["wavelengths"], spectra[2]["wavelengths"])
+    np.testing.assert_array_equal(got[2]["pixel_mask"], spectra[3]["pixel_mask"])
+    np.testing.assert_array_equal(got[0]["noise_variance"], spectra[0]["noise_variance"])
+    assert np.array_equal(np.isnan(got[0]["flux"]), np.isnan(spectra[0]["flux"]))
+    by_index = io.load_preloaded_qsos(str(tmp_path / "p.mat"), z, test_ind=np.array([4, 0]))
+    np.testing.assert_array_equal(by_index[0]["wavelengths"], spectra[4]["wavelengths"])
+
+
+def test_processed_qsos_v73_as_the_consumer_indexes_it(tmp_path):
+    """processed_qsos_*.mat as -v7.3, opened the way CDDF_analysis does (qso_loader.py:84-112,
+    calc_cddf.py:217-220): ``f[name][0, :]`` for column vectors, ``f['model_posteriors'][()].T``,
+    ``f['test_ind'][0, :]``, ``sample_log_likelihoods_dla`` as [S, nq]."""
+    from gp_dla_detection_amd import hdf5
+    rng = np.random.default_rng(2)
+    nq, S = 6, 40
+    res = {k: rng.standard_normal(nq) for k in io.SAVED_VARIABLES}
+    res["sample_log_likelihoods_dla"] = rng.standard_normal((nq, S))
+    res["model_posteriors"] = rng.uniform(size=(nq, 2))
+    res.update(num_lines=3, max_z_cut=0.01, prior_z_qso_increase=0.1,
+               MAP_inds=np.arange(1.0, nq + 1), MAP_z_dlas=rng.uniform(2, 3, nq), MAP_log_nhis=rng.uniform(20, 22, nq))
+    test_ind = np.array([True, False, True, True, False, True, True, True, False])
+    p = str(tmp_path / "processed_qsos_dr12q.mat")
+    io.save_processed_qsos(p, res, test_ind=test_ind, test_set_name="dr12q", training_release="dr12q",
+                           release="dr12q", training_set_name="dr9q_minus_concordance",
+                           dla_catalog_name="dr9q_concordance", prior_ind="prior_catalog.in_dr9")
+    with hdf5.File(p) as f:  # h5py-style indexing
+        assert f.userblock()[:10] == b"MATLAB 7.3"
+        np.testing.assert_array_equal(f["test_ind"][0, :].astype(bool), test_ind)
+        np.testing.assert_array_equal(f["p_dlas"][0, :], res["p_dlas"])
+        np.testing.assert_array_equal(f["min_z_dlas"][0, :], res["min_z_dlas"])
+        np.testing.assert_array_equal(f["model_posteriors"][()].T, res["model_posteriors"])
+        assert f["sample_log_likelihoods_dla"].shape == (S, nq)
+        np.testing.assert_array_equal(f["sample_log_likelihoods_dla"][:, 2], res["sample_log_likelihoods_dla"][2])
+        assert f["num_lines"][0, 0] == 3
+    back = io.load_processed_qsos(p)
+    assert back["test_set_name"] == "dr12q" and back["prior_ind"] == "prior_catalog.in_dr9"
+    for k in io.SAVED_VARIABLES + ("MAP_inds", "MAP_z_dlas"):
+        np.testing.assert_array_equal(back[k], res[k])
+
+
+def test_processed_qsos_multi_v73(tmp_path):
+    """The multi-DLA variable list (multi :498-523) with MATLAB's axis order: sample table
+    [nq x S x max_dlas] read back as [max_dlas, S, nq] (calc_cddf.py:266), base_sample_inds uint32
+    [nq x S x max_dlas-1] (:116), MAP_* [nq x model x slot] (qso_loader.py:107-109)."""
+    from gp_dla_detection_amd import hdf5
+    rng = np.random.default_rng(3)
+    nq, S, md = 5, 24, 4
+    res = {k: rng.standard_normal(nq) for k in io.SAVED_VARIABLES_MULTI}
+    res["sample_log_likelihoods_dla"] = rng.standard_normal((nq, md, S))
+    res["sample_log_likelihoods_lls"] = rng.standard_normal((nq, S))
+    res["base_sample_inds"] = rng.integers(1, S + 1, size=(nq, md - 1, S)).astype(np.uint32)
+    for k in ("log_priors_dla", "log_likelihoods_dla", "log_posteriors_dla"):
+        res[k] = rng.standard_normal((nq, md))
+    res["model_posteriors"] = rng.uniform(size=(nq, 2 + md))
+    for k in ("MAP_z_dlas", "MAP_log_nhis", "MAP_inds"):
+        res[k] = rng.standard_normal((nq, md, md))
+    res["all_exceptions"] = np.array([np.nan, 1.0, np.nan, np.nan, np.nan])
+    p = str(tmp_path / "processed_qsos_multi_meanflux.mat")
+    io.save_processed_qsos_multi(p, res, test_ind=np.ones(nq, bool), k=20, num_dla_samples=S,
+                                 test_set_name="dr12q")
+    with hdf5.File(p) as f:
+        assert f["sample_log_likelihoods_dla"].shape == (md, S, nq)
+        np.testing.assert_array_equal(f["sample_log_likelihoods_dla"][1, :, 3], res["sample_log_likelihoods_dla"][3, 1])
+        assert f["base_sample_inds"].shape == (md - 1, S, nq) and f["base_sample_inds"].dtype == np.dtype("<u4")
+        assert f["base_sample_inds"].attrs["MATLAB_class"] == "uint32"
+        np.testing.assert_array_equal(f["MAP_log_nhis"][()].T, res["MAP_log_nhis"])
+        np.testing.assert_array_equal(f["model_posteriors"][()].T, res["model_posteriors"])
+        np.testing.assert_array_equal(f["p_lls"][0, :], res["p_lls"])
+    back = io.load_processed_qsos(p)
+    for k in ("sample_log_likelihoods_dla", "base_sample_inds", "MAP_inds", "log_likelihoods_dla", "all_exceptions"):
+        np.testing.assert_array_equal(back[k], res[k])
