@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -16,6 +17,7 @@
 #include "../../include/gpdla.h"
 #include "../../include/gpdla_lyman_series.h"
 #include "multi_kernels.hpp"
+#include "sweep_split_kernel.hpp"
 #include "training_kernels.hpp"
 
 using namespace gpdla;
@@ -514,6 +516,29 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   return GPDLA_OK;
 }
 
+// k_sweep_split: 20 < k <= 40 in fp64 (shared Voigt/weight pipeline across the four tile-split waves)
+template <int LINES>
+int launch_sweep_split(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
+  const size_t loop_doubles = sweep_split_lds_doubles(LINES > 0 ? 0 : args.num_lines);
+  using ES = EpilogueShape<52, 4>;
+  const size_t epi_doubles = kExpTab + (size_t)2 * ES::SPP * ES::stride(56);
+  const size_t lds = std::max(loop_doubles, epi_doubles) * sizeof(double);
+  if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "split sweep needs %zu B of LDS", lds);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_split<LINES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.blocks_per_quasar = (int32_t)((b->S + 1 + 2 * kSamplesPerWave - 1) / (2 * kSamplesPerWave));
+  const int64_t nblocks = 8 * ((b->nq + 7) / 8) * (int64_t)args.blocks_per_quasar;
+  if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "batch too large for one launch");
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL((k_sweep_split<LINES>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  HIP_TRY(hipGetLastError());
+  if (c->timing) {
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->have_timing = true;
+  }
+  return GPDLA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -597,6 +622,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.nhi_samples = c->d_nhi;
   sa.perm = c->d_perm;
   sa.order = b->d_order;
+  sa.pix = b->d_pix;
   sa.S = b->S;
   sa.nq = b->nq;
   sa.k = b->k;
@@ -612,8 +638,15 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
     if (!f32) rc = three ? launch_sweep<double, 8, 14, 1, 4, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
     else rc = three ? launch_sweep<float, 8, 14, 1, 4, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
   } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles
-    if (!f32)  // fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
-      rc = three ? launch_sweep<double, 8, 14, 4, 2, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
+    if (!f32) {  // fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
+      // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k_sweep form in which every wave of a group repeats
+      // the Voigt/weight arithmetic, for A/B timing against k_sweep_split
+      static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
+      if (legacy)
+        rc = three ? launch_sweep<double, 8, 14, 4, 2, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
+      else
+        rc = three ? launch_sweep_split<3>(c, b, sa) : launch_sweep_split<0>(c, b, sa);
+    }
     else       // fp32: 224 accumulator registers fit one wave (4-wave blocks, one wave per SIMD)
       rc = three ? launch_sweep<float, 4, 56, 1, 4, 52, 3>(c, b, sa) : launch_sweep<float, 4, 56, 1, 4, 52, 0>(c, b, sa);
   } else {

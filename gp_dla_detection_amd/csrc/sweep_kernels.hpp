@@ -431,6 +431,7 @@ struct SweepArgs {
   const double *nhi_samples;      // [S]
   const int32_t *perm;            // [S] sample indices in ascending offset (= z_DLA) order
   const int32_t *order;           // [nq] quasar indices in order of decreasing pixel count
+  const PixelRow *pix;            // per-pixel pool (k_sweep_split reads rows directly)
   int64_t S;
   int64_t nq;
   int32_t blocks_per_quasar;
