@@ -19,6 +19,7 @@
 #include "multi_kernels.hpp"
 #include "sweep_split_kernel.hpp"
 #include "training_kernels.hpp"
+#include "training_mfma_kernels.hpp"
 
 using namespace gpdla;
 
@@ -1146,10 +1147,17 @@ void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uin
 struct gpdla_training {
   int device_id = 0;
   int64_t nq = 0, G = 0;
-  double *d_flux = nullptr, *d_lya = nullptr, *d_noise = nullptr;
+  double *d_flux = nullptr, *d_lya = nullptr, *d_noise = nullptr, *d_loglya = nullptr;
   double *d_x = nullptr, *d_g = nullptr, *d_omega2 = nullptr, *d_f = nullptr;
   int32_t *d_flag = nullptr;
   int64_t x_capacity = 0;
+  // workspace of the matrix-core path (training_mfma_kernels.hpp), allocated for the first k seen
+  int ws_k = 0;
+  double *h_stage = nullptr;  // pinned host staging for x (in) and [g | f | flag] (out)
+  int64_t stage_capacity = 0;
+  double *d_wA = nullptr, *d_uA = nullptr, *d_wB = nullptr, *d_uB = nullptr, *d_part1 = nullptr;
+  double *d_recM = nullptr, *d_recP = nullptr, *d_partB = nullptr, *d_recD = nullptr, *d_recE = nullptr;
+  double *d_nlogp = nullptr, *d_partD = nullptr, *d_partcol = nullptr, *d_partsc = nullptr;
 };
 
 extern "C" {
@@ -1159,8 +1167,12 @@ void gpdla_training_destroy(gpdla_training *t) {
   (void)hipSetDevice(t->device_id);
   (void)hipDeviceSynchronize();
   for (void *p : {(void *)t->d_flux, (void *)t->d_lya, (void *)t->d_noise, (void *)t->d_x, (void *)t->d_g,
-                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag})
+                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag, (void *)t->d_loglya, (void *)t->d_wA, (void *)t->d_uA,
+                  (void *)t->d_wB, (void *)t->d_uB, (void *)t->d_part1, (void *)t->d_recM, (void *)t->d_recP,
+                  (void *)t->d_partB, (void *)t->d_recD, (void *)t->d_recE, (void *)t->d_nlogp,
+                  (void *)t->d_partD, (void *)t->d_partcol, (void *)t->d_partsc})
     dev_free(p);
+  if (t->h_stage) (void)hipHostFree(t->h_stage);
   delete t;
 }
 
@@ -1186,7 +1198,16 @@ int gpdla_training_create(int device_id, int64_t nq, int64_t G, const double *fl
     HIP_TRY(hipMemcpy(*dst, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
     return GPDLA_OK;
   };
+  auto up_log = [&](const double *src, double **dst) -> int {  // log(1 + z): data, taken once
+    for (int64_t i = 0; i < nq; ++i)
+      for (int64_t p = 0; p < G; ++p) tmp[(size_t)i * G + p] = std::log(src[i + p * nq]);
+    int r = dev_alloc(dst, n);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(*dst, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    return GPDLA_OK;
+  };
   if ((rc = up(flux, &t->d_flux)) || (rc = up(lya, &t->d_lya)) || (rc = up(noise, &t->d_noise)) ||
+      (rc = up_log(lya, &t->d_loglya)) ||
       (rc = dev_alloc(&t->d_omega2, (size_t)G)) || (rc = dev_alloc(&t->d_f, 1)) ||
       (rc = dev_alloc(&t->d_flag, 1))) {
     gpdla_training_destroy(t);
@@ -1195,6 +1216,138 @@ int gpdla_training_create(int device_id, int64_t nq, int64_t G, const double *fl
   *out = t;
   return GPDLA_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+TrainDims train_dims(const gpdla_training *t, int k) {
+  TrainDims d;
+  d.nq = t->nq;
+  d.G = t->G;
+  d.k = k;
+  d.NQ16 = (t->nq + 15) / 16;
+  d.PG = (t->G + 15) / 16;
+  d.T = 4 * d.PG;
+  d.TQ = 4 * d.NQ16;
+  d.PB = (16 * d.PG + 63) / 64;
+  d.H = 6;    // 79 row blocks x 6 = 474 blocks of 4 waves for 5000 quasars (two per CU)
+  d.H2 = 24;  // 20 row blocks x 24 = 480
+  d.GS = 24;  // 20 pixel blocks x 24 = 480 blocks of 4 waves (59 KiB of LDS each: two per CU)
+  return d;
+}
+
+// objective.m:12-75 on the matrix cores (k <= 20): value and gradient, deterministic.
+int training_objective_mfma(gpdla_training *t, const double *x, int k, double *f, double *g) {
+  const TrainDims d = train_dims(t, k);
+  const int64_t G = t->G;
+  int rc;
+  if (!t->d_wA) {
+    const size_t tiled = (size_t)d.NQ16 * d.T * 64;
+    if ((rc = dev_alloc(&t->d_wA, tiled)) || (rc = dev_alloc(&t->d_uA, tiled)) ||
+        (rc = dev_alloc(&t->d_wB, (size_t)d.PG * d.TQ * 64)) || (rc = dev_alloc(&t->d_uB, (size_t)d.PG * d.TQ * 64)) ||
+        (rc = dev_alloc(&t->d_part1, (size_t)d.NQ16 * 16 * d.PB * 3)) ||
+        (rc = dev_alloc(&t->d_recM, (size_t)d.T * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recP, (size_t)d.PG * kTrKs * 64)) ||
+        (rc = dev_alloc(&t->d_partB, (size_t)d.NQ16 * d.H * 16 * kTrCols)) ||
+        (rc = dev_alloc(&t->d_recD, (size_t)d.TQ * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recE, (size_t)d.NQ16 * kTrKs * 64)) ||
+        (rc = dev_alloc(&t->d_nlogp, (size_t)d.NQ16 * 16)) ||
+        (rc = dev_alloc(&t->d_partD, (size_t)d.PG * d.H2 * 16 * kTrCols)) ||
+        (rc = dev_alloc(&t->d_partcol, (size_t)d.PG * d.GS * 16)) || (rc = dev_alloc(&t->d_partsc, (size_t)d.PG * d.GS * 3)))
+      return rc;
+  }
+  const double c_0 = std::exp(x[G * (k + 1)]), tau_0 = std::exp(x[G * (k + 1) + 1]), beta = std::exp(x[G * (k + 1) + 2]);
+  HIP_TRY(hipMemsetAsync(t->d_flag, 0, sizeof(int32_t), 0));
+  hipLaunchKernelGGL(k_training_omega2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, 0, t->d_x + G * k, G, t->d_omega2);
+  TrainPrepareArgs pa;
+  pa.d = d;
+  pa.flux = t->d_flux;
+  pa.log_lya_1pz = t->d_loglya;
+  pa.noise = t->d_noise;
+  pa.omega2 = t->d_omega2;
+  pa.c_0 = c_0;
+  pa.tau_0 = tau_0;
+  pa.beta = beta;
+  pa.wA = t->d_wA;
+  pa.uA = t->d_uA;
+  pa.wB = t->d_wB;
+  pa.uB = t->d_uB;
+  pa.part1 = t->d_part1;
+  hipLaunchKernelGGL(k_train_prepare, dim3((unsigned)(d.NQ16 * d.PB)), dim3(256), 0, 0, pa);
+  TrainRecordsArgs ra;
+  ra.d = d;
+  ra.M = t->d_x;
+  ra.recM = t->d_recM;
+  ra.recP = t->d_recP;
+  hipLaunchKernelGGL(k_train_records, dim3(1024), dim3(256), 0, 0, ra);
+  TrainContractArgs ca;  // B_q, t_q: rows = quasars, steps over pixels
+  ca.Aw = t->d_wA;
+  ca.Au = t->d_uA;
+  ca.Brec = t->d_recM;
+  ca.R = d.NQ16;
+  ca.steps = d.T;
+  ca.nsplit = d.H;
+  ca.out = t->d_partB;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_contract),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrContractLds));
+  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H)), dim3(kTrCWaves * 64), kTrContractLds, 0, ca);
+  TrainFactorArgs fa;
+  fa.d = d;
+  fa.partB = t->d_partB;
+  fa.part1 = t->d_part1;
+  fa.recD = t->d_recD;
+  fa.recE = t->d_recE;
+  fa.nlogp = t->d_nlogp;
+  fa.not_pd = t->d_flag;
+  hipLaunchKernelGGL(k_train_factor<20>, dim3((unsigned)(d.NQ16 * 16 / kTrFQ)), dim3(kTrFQ * 64), 0, 0, fa);
+  ca.Aw = t->d_wB;  // dM: rows = pixels, steps over quasars
+  ca.Au = t->d_uB;
+  ca.Brec = t->d_recD;
+  ca.R = d.PG;
+  ca.steps = d.TQ;
+  ca.nsplit = d.H2;
+  ca.out = t->d_partD;
+  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.PG + kTrCWaves - 1) / kTrCWaves) * d.H2)), dim3(kTrCWaves * 64), kTrContractLds, 0, ca);
+  TrainCoreArgs co;
+  co.d = d;
+  co.recP = t->d_recP;
+  co.recE = t->d_recE;
+  co.flux = t->d_flux;
+  co.log_lya_1pz = t->d_loglya;
+  co.noise = t->d_noise;
+  co.omega2 = t->d_omega2;
+  co.c_0 = c_0;
+  co.tau_0 = tau_0;
+  co.beta = beta;
+  co.partcol = t->d_partcol;
+  co.partsc = t->d_partsc;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_core),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrCoreLds));
+  hipLaunchKernelGGL(k_train_core, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), kTrCoreLds, 0, co);
+  TrainFinishArgs fi;
+  fi.d = d;
+  fi.M = t->d_x;
+  fi.partD = t->d_partD;
+  fi.partcol = t->d_partcol;
+  fi.partsc = t->d_partsc;
+  fi.nlogp = t->d_nlogp;
+  const int64_t nx = G * (k + 1) + 3;
+  fi.f = t->d_g + nx;        // f and the not-PD flag ride behind g: one copy back
+  fi.flag_in = t->d_flag;
+  fi.flag_out = t->d_g + nx + 1;
+  fi.g = t->d_g;
+  hipLaunchKernelGGL(k_train_finish, dim3((unsigned)(G + 1)), dim3(256), 0, 0, fi);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(t->h_stage, t->d_g, (size_t)(nx + 2) * sizeof(double), hipMemcpyDeviceToHost));
+  std::memcpy(g, t->h_stage, (size_t)nx * sizeof(double));
+  *f = t->h_stage[nx];
+  if (t->h_stage[nx + 1] != 0.0)
+    return fail(GPDLA_ERR_NOT_POSITIVE_DEFINITE, "B = I + M' D^-1 M not positive definite for some quasar");
+  return GPDLA_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *f, double *g) {
   if (!t || !x || !f || !g) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
@@ -1207,10 +1360,27 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
     dev_free(t->d_g);
     t->d_x = t->d_g = nullptr;
     int rc;
-    if ((rc = dev_alloc(&t->d_x, (size_t)nx)) || (rc = dev_alloc(&t->d_g, (size_t)nx))) return rc;
+    if ((rc = dev_alloc(&t->d_x, (size_t)nx)) || (rc = dev_alloc(&t->d_g, (size_t)nx + 2))) return rc;
     t->x_capacity = nx;
+    if (t->h_stage) (void)hipHostFree(t->h_stage);
+    t->h_stage = nullptr;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&t->h_stage), (size_t)(nx + 2) * sizeof(double), hipHostMallocDefault));
   }
-  HIP_TRY(hipMemcpy(t->d_x, x, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
+  std::memcpy(t->h_stage, x, (size_t)nx * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(t->d_x, t->h_stage, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, 0));
+  // k <= 20: the three contractions on the matrix cores, ordered (deterministic) sums.
+  // GPDLA_TRAIN_LEGACY=1 (diagnostic) or k > 20: one block per quasar, fp64 atomics into g.
+  static const bool legacy = std::getenv("GPDLA_TRAIN_LEGACY") != nullptr;
+  if (k <= 20 && !legacy) {
+    if (t->ws_k == 0) t->ws_k = k;
+    int rc = training_objective_mfma(t, x, k, f, g);
+    if (rc) return rc;
+    const double tau_0 = std::exp(x[G * (k + 1) + 1]), beta = std::exp(x[G * (k + 1) + 2]);
+    const double tau_0_mu = 0.0023, tau_0_sigma = 0.0007, beta_mu = 3.65, beta_sigma = 0.21;  // objective.m:59-71
+    g[G * (k + 1) + 1] += tau_0 * (tau_0 - tau_0_mu) / (tau_0_sigma * tau_0_sigma);
+    g[G * (k + 1) + 2] += beta * (beta - beta_mu) / (beta_sigma * beta_sigma);
+    return GPDLA_OK;
+  }
   HIP_TRY(hipMemset(t->d_g, 0, (size_t)nx * sizeof(double)));
   HIP_TRY(hipMemset(t->d_f, 0, sizeof(double)));
   HIP_TRY(hipMemset(t->d_flag, 0, sizeof(int32_t)));

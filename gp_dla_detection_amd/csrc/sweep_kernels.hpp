@@ -339,43 +339,64 @@ __host__ __device__ constexpr int record_doubles(int ntiles, int f32_tiles) {
 }
 
 __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
+  // One block builds whole records (steps bq, bq + blocks_per_quasar, ...): the four M rows of a
+  // step are staged in LDS, the (i, j) of every vech column comes from a table built once per
+  // block, and every thread writes 16 bytes at a time -- the kernel is a pure HBM write stream.
+  constexpr int SB = 8;  // steps staged per pair of barriers
+  __shared__ double s_rows[SB * 4][GPDLA_MAX_K];
+  __shared__ uint8_t s_vi[52 * 16], s_vj[52 * 16];
   const int q = blockIdx.x / a.blocks_per_quasar;
   const int bq = blockIdx.x % a.blocks_per_quasar;
   const QuasarMeta m = a.meta[q];
+  const int tid = threadIdx.x;
   const int RD = record_doubles(a.ntiles, a.f32_tiles);
   const int xtra = record_extras(a.ntiles);
-  const int per_rec = a.ntiles * 64 + xtra;  // logical elements per record
-  const int64_t total = (int64_t)(m.steps + 1) * per_rec;
   const int ncol_w = a.k * (a.k + 1) / 2;
   const int n_pad = m.n_u + 6;
+  const int k = a.k;
+  for (int c = tid; c < a.tiles_w * 16; c += 256) {
+    int i = 0, j = 0;
+    if (c < ncol_w) {
+      i = (int)((sqrt(8.0 * c + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= c) ++i;
+      while (i * (i + 1) / 2 > c) --i;
+      j = c - i * (i + 1) / 2;
+    }
+    s_vi[c] = (uint8_t)i;
+    s_vj[c] = (uint8_t)j;
+  }
   double *out = a.records + (m.pix_off / 4) * (int64_t)RD;
-  for (int64_t e = (int64_t)bq * 256 + threadIdx.x; e < total;
-       e += (int64_t)a.blocks_per_quasar * 256) {
-    const int step = (int)(e / per_rec);
-    const int rem = (int)(e - (int64_t)step * per_rec);
-    double *rec = out + (int64_t)step * RD;
-    double v = 0.0;
-    if (rem < a.ntiles * 64) {
+  const int nrec = m.steps + 1;  // record `steps` is the neutral trailing one
+  for (int step0 = bq * SB; step0 < nrec; step0 += a.blocks_per_quasar * SB) {
+    const int nst = min(SB, nrec - step0);
+    __syncthreads();  // previous rows consumed (and, first time, the table complete)
+    for (int e = tid; e < nst * 4 * k; e += 256)  // rows 4 step0 .. of Mi are contiguous
+      s_rows[e / k][e % k] = a.Mi[(m.pix_off + 4 * (int64_t)step0) * k + e];
+    __syncthreads();
+    const int per = a.ntiles * 32;  // 16-byte units of tiles per record
+    for (int u = tid; u < nst * per; u += 256) {
+      const int ls = u / per, rem = 2 * (u - ls * per);  // two neighbouring columns of one pixel
       const int tile = rem >> 6, l = rem & 63;
       const int jj = l >> 4, col = l & 15;
-      const double *row = a.Mi + (m.pix_off + 4 * (int64_t)step + jj) * a.k;
+      const double *row = s_rows[ls * 4 + jj];
+      double v0 = 0.0, v1 = 0.0;
       if (tile < a.tiles_w) {
         const int c = tile * 16 + col;
-        if (c < ncol_w) {
-          int i = (int)((sqrt(8.0 * c + 1.0) - 1.0) * 0.5);
-          while ((i + 1) * (i + 2) / 2 <= c) ++i;
-          while (i * (i + 1) / 2 > c) --i;
-          const int j = c - i * (i + 1) / 2;
-          v = row[i] * row[j];
-        }
+        if (c < ncol_w) v0 = row[s_vi[c]] * row[s_vj[c]];
+        if (c + 1 < ncol_w) v1 = row[s_vi[c + 1]] * row[s_vj[c + 1]];
       } else {
         const int c = (tile - a.tiles_w) * 16 + col;
-        if (c < a.k) v = row[c];
+        if (c < k) v0 = row[c];
+        if (c + 1 < k) v1 = row[c + 1];
       }
-      if (a.f32_tiles) reinterpret_cast<float *>(rec)[rem] = (float)v;
-      else rec[rem] = v;
-    } else {
-      const int r2 = rem - a.ntiles * 64;
+      double *rec = out + (int64_t)(step0 + ls) * RD;
+      if (a.f32_tiles) *reinterpret_cast<float2 *>(reinterpret_cast<float *>(rec) + rem) = make_float2((float)v0, (float)v1);
+      else *reinterpret_cast<double2 *>(rec + rem) = make_double2(v0, v1);
+    }
+    for (int e = tid; e < nst * xtra; e += 256) {
+      const int ls = e / xtra, r2 = e - ls * xtra;
+      const int step = step0 + ls;
+      double v = 0.0;
       if (r2 < 16) {
         const PixelRow px = a.pix[m.pix_off + 4 * (int64_t)step + (r2 >> 2)];
         const int f = r2 & 3;
@@ -388,14 +409,14 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
         const bool is_w = r2 < 32;
         const int jj = is_w ? (r2 - 24) >> 1 : (r2 - 32) >> 2;
         const int x = is_w ? (r2 - 24) & 1 : (r2 - 32) & 3;
-        const double *row = a.Mi + (m.pix_off + 4 * (int64_t)step + jj) * a.k;
+        const double *row = s_rows[ls * 4 + jj];
         if (is_w) {  // vech index 208 + x = (19, 18 + x)
           if (kXWColumn + x < ncol_w) v = row[19] * row[18 + x];
-        } else if (kXUColumn + x < a.k) {
+        } else if (kXUColumn + x < k) {
           v = row[kXUColumn + x];
         }
       }
-      rec[RD - xtra + r2] = v;
+      out[(int64_t)step * RD + RD - xtra + r2] = v;
     }
   }
 }

@@ -1,0 +1,668 @@
+// training_mfma_kernels.hpp -- the training objective (objective.m:12-75 over spectrum_loss.m:14-76)
+// on the fp64 matrix cores, value and gradient, deterministic (no atomics).
+//
+// All training quasars share the rest-frame pixel grid and M, so the per-quasar Woodbury pieces of
+// spectrum_loss.m are three dense contractions over the whole training set -- the sweep's
+// [W | U] . [P | M] with "samples" replaced by quasars:
+//
+//   d = nu + omega2 (1 - exp(-tau0 (1+z)^beta) + c0)^2,   w = 1/d,   u = y/d          (:22-32)
+//   B_q = I + Sum_p w_qp m_p m_p',   t_q = Sum_p u_qp m_p      contraction over pixels  (:40)
+//   L_q = chol(B_q),  z_q = B_q^-1 t_q,  T_q = B_q^-1 + z_q z_q'   per quasar, k x k    (:42-46)
+//   -log p_q = 1/2 (Sum y^2 w - t_q'z_q + Sum log d + 2 Sum log L_jj + n log 2 pi)      (:48-52)
+//   dM[p,:] = m_p' (Sum_q w_qp T_q) - Sum_q u_qp z_q'          contraction over quasars (:55-56)
+//   core_qp = (K^-1 y)_p^2 - (K^-1)_pp = u^2 - 2 u w (m_p'z_q) + w^2 (m_p'T_q m_p) - w  (:59)
+//   dlog_omega[p] = -Sum_q an_qp core_qp, dlog_c0 / tau0 / beta = -Sum_qp core_qp da_qp  (:62-74)
+//
+// using K^-1 M = D^-1 M B^-1, M'K^-1 y = z, y'K^-1 y = Sum y^2 w - t'z (identities of the Woodbury
+// form; the as-written k x n matrix C of :44 is never formed).  m'T m is the dot product of
+// vech(m m') with vech(T) (off-diagonals doubled), i.e. the third contraction -- over the
+// k(k+1)/2 + k columns -- and every contraction runs on v_mfma_f64_16x16x4_f64.
+//
+// Kernels (k <= 20; 14 w-tiles + 2 u-tiles of 16 columns):
+//   k_train_prepare   elementwise w, u from (flux, 1+z, noise); written in the two lane-ordered
+//                     tilings the contractions read, through an LDS transpose; per-quasar partial
+//                     sums of log d, y^2 w and the pixel count
+//   k_train_records   [vech(m m') | m] from M in the two B-operand tilings
+//   k_train_contract  rows x steps MFMA contraction, used twice: B/t (rows = quasars, steps over
+//                     pixels) and dM (rows = pixels, steps over quasars); split along the step axis
+//                     into partial sums that the next kernel adds in a fixed order
+//   k_train_factor    per quasar: Cholesky, B^-1, z, -log p; T_q and z_q in both operand tilings
+//   k_train_core      m'z and m'Tm by MFMA, then the element-wise gradient terms and their sums
+//   k_train_finish    ordered sums of all partials into f and g
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sweep_kernels.hpp"
+
+namespace gpdla {
+
+constexpr int kTrW = 14, kTrU = 2, kTrTiles = kTrW + kTrU;  // B tiles per contraction step
+constexpr int kTrCols = kTrTiles * 16;                      // 256 columns: 224 vech + 32 projection
+constexpr int kTrKsW = 53, kTrKsU = 5, kTrKs = kTrKsW + kTrKsU;  // column steps of the core contraction
+
+struct TrainDims {
+  int64_t nq, G;      // quasars, pixels
+  int32_t k;
+  int64_t NQ16, PG;   // row groups of 16: quasars, pixels
+  int64_t T, TQ;      // contraction steps of 4: pixels (4 PG), quasars (4 NQ16)
+  int64_t PB;         // 64-pixel blocks of k_train_prepare
+  int32_t H, H2, GS;  // splits: B build over pixels, dM over quasars, core over quasar groups
+};
+
+__host__ __device__ inline void vech_ij(int c, int *i, int *j) {
+  int ii = (int)((sqrt(8.0 * c + 1.0) - 1.0) * 0.5);
+  while ((ii + 1) * (ii + 2) / 2 <= c) ++ii;
+  while (ii * (ii + 1) / 2 > c) --ii;
+  *i = ii;
+  *j = c - ii * (ii + 1) / 2;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_train_prepare: block = (quasar group g of 16, block pb of 64 pixels), 256 threads.
+// wA/uA: [NQ16][T][jj = pixel % 4][s = quasar % 16]     A operand of the B build
+// wB/uB: [PG][TQ][jj = quasar % 4][s = pixel % 16]      A operand of the dM contraction
+// part1: [16 NQ16][PB][3] = (Sum log d, Sum y^2 w, count) of the block's pixels
+// ------------------------------------------------------------------------------------------
+struct TrainPrepareArgs {
+  TrainDims d;
+  const double *flux, *log_lya_1pz, *noise;  // [nq][G], NaN flux = missing pixel (objective.m:42)
+  const double *omega2;                      // [G]
+  double c_0, tau_0, beta;
+  double *wA, *uA, *wB, *uB, *part1;
+};
+
+// (log(1+z) is data: it is taken once, when the training set is uploaded, so that the power of
+// spectrum_loss.m:22 costs one exp per evaluation instead of a pow)
+__device__ __forceinline__ void train_element(double y, double logz1, double nu, double om, double c_0,
+                                              double tau_0, double beta, double *w, double *u, double *d_out) {
+  const double od = tau_0 * fast_rcp(exp_nonpos(-beta * logz1));  // spectrum_loss.m:22: tau0 (1+z)^beta
+  const double sf = 1 - exp_nonpos(-od) + c_0;  // :23, :26
+  const double d = nu + om * (sf * sf);         // :27, :29
+  *w = fast_rcp(d);                             // :31
+  *u = *w * y;                                // :32
+  *d_out = d;
+}
+
+__global__ __launch_bounds__(256) void k_train_prepare(TrainPrepareArgs a) {
+  __shared__ double sw[16][65], su[16][65];
+  const TrainDims &D = a.d;
+  const int64_t g = blockIdx.x / D.PB, pb = blockIdx.x % D.PB;
+  const int tid = threadIdx.x, pl = tid & 63, wv = tid >> 6;
+  const int64_t p = pb * 64 + pl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ql = wv + 4 * i;
+    const int64_t q = g * 16 + ql;
+    double w = 0.0, u = 0.0, logd = 0.0, yy = 0.0, cnt = 0.0;
+    if (q < D.nq && p < D.G) {
+      const double y = a.flux[q * D.G + p];
+      if (!isnan(y)) {
+        double d;
+        train_element(y, a.log_lya_1pz[q * D.G + p], a.noise[q * D.G + p], a.omega2[p], a.c_0, a.tau_0, a.beta,
+                      &w, &u, &d);
+        logd = log(d);
+        yy = y * u;
+        cnt = 1.0;
+      }
+    }
+    sw[ql][pl] = w;
+    su[ql][pl] = u;
+    for (int o = 32; o > 0; o >>= 1) {  // the wave holds 64 pixels of ONE quasar
+      logd += __shfl_xor(logd, o);
+      yy += __shfl_xor(yy, o);
+      cnt += __shfl_xor(cnt, o);
+    }
+    if (pl == 0) {
+      double *o3 = a.part1 + ((g * 16 + ql) * D.PB + pb) * 3;
+      o3[0] = logd;
+      o3[1] = yy;
+      o3[2] = cnt;
+    }
+  }
+  __syncthreads();
+  // tiling A: 16 steps of this pixel block, 64 doubles each: [jj][s] = (pixel 4 t + jj, quasar s)
+  for (int e = tid; e < 16 * 64; e += 256) {
+    const int tl = e >> 6, l = e & 63, jj = l >> 4, s = l & 15;
+    const int64_t t = pb * 16 + tl;
+    if (t < D.T) {
+      a.wA[(g * D.T + t) * 64 + l] = sw[s][4 * tl + jj];
+      a.uA[(g * D.T + t) * 64 + l] = su[s][4 * tl + jj];
+    }
+  }
+  // tiling B: 4 pixel groups x 4 quasar steps, 64 doubles each: [jj][s] = (quasar 4 tq + jj, pixel s)
+  for (int e = tid; e < 16 * 64; e += 256) {
+    const int blk = e >> 6, l = e & 63, jj = l >> 4, s = l & 15;
+    const int pgl = blk >> 2, tql = blk & 3;
+    const int64_t pg = pb * 4 + pgl, tq = g * 4 + tql;
+    if (pg < D.PG) {
+      a.wB[(pg * D.TQ + tq) * 64 + l] = sw[4 * tql + jj][16 * pgl + s];
+      a.uB[(pg * D.TQ + tq) * 64 + l] = su[4 * tql + jj][16 * pgl + s];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_train_records: from M (G x k column-major)
+// recM: [T][16 tiles][jj = pixel % 4][col]   B[pixel 4t+jj][column 16c+col] of [vech(m m') | m]
+// recP: [PG][58 column steps][jj][col]        B[column 4ks+jj][pixel 16pt+col], vech then m
+// ------------------------------------------------------------------------------------------
+struct TrainRecordsArgs {
+  TrainDims d;
+  const double *M;
+  double *recM, *recP;
+};
+
+__device__ __forceinline__ double train_col_value(const double *M, int64_t G, int k, int64_t p, int kind, int idx) {
+  // kind 0: vech column idx of m_p m_p'; kind 1: m_p[idx]
+  if (p >= G) return 0.0;
+  if (kind == 0) {
+    if (idx >= k * (k + 1) / 2) return 0.0;
+    int i, j;
+    vech_ij(idx, &i, &j);
+    return M[p + (int64_t)i * G] * M[p + (int64_t)j * G];
+  }
+  return idx < k ? M[p + (int64_t)idx * G] : 0.0;
+}
+
+__global__ void k_train_records(TrainRecordsArgs a) {
+  const TrainDims &D = a.d;
+  const int64_t nM = D.T * kTrTiles * 64, nP = D.PG * kTrKs * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nM + nP; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < nM) {
+      const int l = (int)(e & 63), c = (int)((e >> 6) % kTrTiles);
+      const int64_t t = (e >> 6) / kTrTiles;
+      const int jj = l >> 4, col = l & 15;
+      a.recM[e] = c < kTrW ? train_col_value(a.M, D.G, D.k, 4 * t + jj, 0, 16 * c + col)
+                           : train_col_value(a.M, D.G, D.k, 4 * t + jj, 1, 16 * (c - kTrW) + col);
+    } else {
+      const int64_t e2 = e - nM;
+      const int l = (int)(e2 & 63), ks = (int)((e2 >> 6) % kTrKs);
+      const int64_t pt = (e2 >> 6) / kTrKs;
+      const int jj = l >> 4, col = l & 15;
+      a.recP[e2] = ks < kTrKsW ? train_col_value(a.M, D.G, D.k, 16 * pt + col, 0, 4 * ks + jj)
+                               : train_col_value(a.M, D.G, D.k, 16 * pt + col, 1, 4 * (ks - kTrKsW) + jj);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_train_contract: out[R][h][16 rows][256 columns] = Sum over this split's steps of
+// [a_w x 14 tiles | a_u x 2 tiles] (rows x 4) . Brec (4 x 256).  A block is 4 waves = 4 row groups
+// that walk the SAME steps (split h), so the B records are staged once per block: chunks of 4
+// steps, double-buffered in LDS by the sweep's asynchronous global->LDS copy (glds16), one
+// barrier per chunk.  64 KiB of LDS per block: two blocks share a CU, so a SIMD always has a wave
+// of the other block to run while one waits at its barrier.  The A operands (512 contiguous bytes
+// per wave and step) come straight from global memory, one chunk ahead.
+// ------------------------------------------------------------------------------------------
+struct TrainContractArgs {
+  const double *Aw, *Au;   // [R][steps][64]
+  const double *Brec;      // [steps][16][64]
+  int64_t R, steps;
+  int32_t nsplit;
+  double *out;             // [R][nsplit][16][256]
+};
+constexpr int kTrChunk = 4;                             // steps per staged chunk
+constexpr int kTrRecD = kTrTiles * 64;                  // doubles per step record
+constexpr int kTrCWaves = 4;                            // row groups (waves) per block
+constexpr size_t kTrContractLds = 2 * kTrChunk * kTrRecD * sizeof(double);  // 64 KiB
+
+__global__ __launch_bounds__(kTrCWaves * 64) void k_train_contract(TrainContractArgs a) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t rb = blockIdx.x / a.nsplit;
+  const int h = (int)(blockIdx.x % a.nsplit);
+  const int64_t r = rb * kTrCWaves + wave;
+  const bool active = r < a.R;
+  const int64_t t0 = (a.steps * h) / a.nsplit, t1 = (a.steps * (h + 1)) / a.nsplit;  // balanced split
+  const int nchunks = (int)((t1 - t0 + kTrChunk - 1) / kTrChunk);
+  d4 acc[kTrTiles];
+#pragma unroll
+  for (int c = 0; c < kTrTiles; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+  const double *aw = a.Aw + ((active ? r : 0) * a.steps) * 64 + lane, *au = a.Au + ((active ? r : 0) * a.steps) * 64 + lane;
+  auto issue_chunk = [&](int c) {
+    const int64_t ts = t0 + (int64_t)c * kTrChunk;
+    const int csteps = (int)min((int64_t)kTrChunk, t1 - ts);
+    const int units = csteps * (kTrRecD / 2);  // 16-byte units
+    const double *src = a.Brec + ts * kTrRecD;
+    double *dst = smem + (size_t)(c & 1) * kTrChunk * kTrRecD;
+    for (int i = wave; i * 64 < units; i += kTrCWaves) {
+      const int unit = i * 64 + lane;
+      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)i * 128);
+    }
+  };
+  double wn[kTrChunk], un[kTrChunk];
+  auto load_a = [&](int c) {
+#pragma unroll
+    for (int tt = 0; tt < kTrChunk; ++tt) {
+      const int64_t t = min(t0 + (int64_t)c * kTrChunk + tt, a.steps - 1);  // clamped: unused beyond t1
+      wn[tt] = aw[t * 64];
+      un[tt] = au[t * 64];
+    }
+  };
+  if (nchunks > 0) {
+    load_a(0);
+    issue_chunk(0);
+  }
+  for (int c = 0; c < nchunks; ++c) {
+    double wc[kTrChunk], uc[kTrChunk];
+#pragma unroll
+    for (int tt = 0; tt < kTrChunk; ++tt) {
+      wc[tt] = wn[tt];
+      uc[tt] = un[tt];
+    }
+    glds_wait();      // chunk c landed (this wave's part) ...
+    __syncthreads();  // ... and everyone's; the other buffer's readers are done
+    if (c + 1 < nchunks) {
+      load_a(c + 1);
+      issue_chunk(c + 1);
+    }
+    const double *buf = smem + (size_t)(c & 1) * kTrChunk * kTrRecD + lane;
+    const int csteps = (int)min((int64_t)kTrChunk, t1 - (t0 + (int64_t)c * kTrChunk));
+#pragma unroll
+    for (int tt = 0; tt < kTrChunk; ++tt) {
+      if (tt < csteps) {
+        double b[kTrTiles];
+#pragma unroll
+        for (int cc = 0; cc < kTrTiles; ++cc) b[cc] = buf[(size_t)(tt * kTrTiles + cc) * 64];
+#pragma unroll
+        for (int cc = 0; cc < kTrTiles; ++cc)
+          acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < kTrW ? wc[tt] : uc[tt], b[cc], acc[cc], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  // result register rr of tile c: row (lane >> 4) + 4 rr, column 16 c + (lane & 15)
+  double *o = a.out + ((r * a.nsplit + h) * 16) * kTrCols;
+  const int jj = lane >> 4, s = lane & 15;
+#pragma unroll
+  for (int c = 0; c < kTrTiles; ++c)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) o[(int64_t)(jj + 4 * rr) * kTrCols + 16 * c + s] = acc[c][rr];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_train_factor: one wave per quasar (padded quasars write zero operands).
+// recD: [TQ][16 tiles][jj = quasar % 4][col]  B[quasar][column] of [vech(T_q) | z_q]   (dM)
+// recE: [NQ16][58][jj = column % 4][s = quasar % 16]  A[quasar][column] of [vech2(T_q) | z_q]  (core)
+// ------------------------------------------------------------------------------------------
+struct TrainFactorArgs {
+  TrainDims d;
+  const double *partB;   // [NQ16][H][16][256]
+  const double *part1;   // [16 NQ16][PB][3]
+  double *recD, *recE, *nlogp;
+  int32_t *not_pd;
+};
+
+constexpr int kTrFQ = 8;  // quasars (waves) per block of k_train_factor
+
+template <int KMAX>
+__global__ __launch_bounds__(kTrFQ * 64) void k_train_factor(TrainFactorArgs a) {
+  // One wave per quasar, 8 quasars per block.  Lane i owns row i of B / L in registers (static
+  // indices: the loops over KMAX are unrolled); pivots and multipliers travel by wave shuffles, L
+  // and L^-1 are shared through LDS for the inverse.  No private array is indexed at run time
+  // (that would live in scratch memory).  The two operand tilings of [T_q | z_q] are assembled in
+  // LDS and leave the block as contiguous runs (8 of the 16 interleaved quasars of recE, two whole
+  // quasar steps of recD).
+  // (s_sum -- the summed partials -- is dead once the rows are in registers and is reused for the
+  // recD rows; the storage of L / L^-1 likewise for the recE rows: 68 KB, two blocks per CU)
+  __shared__ double s_L[kTrFQ][KMAX * KMAX], s_Bi[kTrFQ][KMAX * KMAX], s_sum[kTrFQ][kTrCols], s_t[kTrFQ][KMAX],
+      s_z[kTrFQ][KMAX], s_sc[kTrFQ][4];
+  static_assert(kTrKs * 4 <= KMAX * KMAX, "recE rows must fit the storage of L");
+  double (*s_outD)[kTrCols] = s_sum;
+  double (*s_outE)[KMAX * KMAX] = s_L;
+  __shared__ uint8_t s_vi[kTrW * 16], s_vj[kTrW * 16];
+  const TrainDims &D = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = D.k;
+  const int64_t q0 = (int64_t)blockIdx.x * kTrFQ, q = q0 + wave;
+  const int nb = k * (k + 1) / 2;
+  for (int c = tid; c < kTrW * 16; c += kTrFQ * 64) {
+    int i = 0, j = 0;
+    if (c < nb) vech_ij(c, &i, &j);
+    s_vi[c] = (uint8_t)i;
+    s_vj[c] = (uint8_t)j;
+  }
+  const bool real = q < D.nq;  // wave-uniform
+  const int64_t g = q >> 4;
+  const int qs = (int)(q & 15);
+  const bool mine = lane < k;
+  double *sL = s_L[wave], *sBi = s_Bi[wave], *sum = s_sum[wave], *st = s_t[wave], *sz = s_z[wave];
+  bool pd = true;
+  double logdiag = 0.0;
+  if (real) {
+    // [vech(B - I) | t] = Sum_h partial, in split order; lanes along the 256 columns (coalesced)
+    const double *pb = a.partB + ((g * D.H) * 16 + qs) * kTrCols;
+#pragma unroll
+    for (int e = 0; e < kTrCols / 64; ++e) {
+      double v = 0.0;
+      for (int h = 0; h < D.H; ++h) v += pb[(int64_t)h * 16 * kTrCols + e * 64 + lane];
+      sum[e * 64 + lane] = v;
+    }
+    if (lane < 3) {
+      double v = 0.0;
+      for (int64_t b = 0; b < D.PB; ++b) v += a.part1[(q * D.PB + b) * 3 + lane];
+      s_sc[wave][lane] = v;
+    }
+  }
+  __syncthreads();
+  double x[KMAX];
+  if (real) {
+    double row[KMAX];  // row `lane` of B (lower triangle)
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      double v = 0.0;
+      if (mine && j <= lane) {
+        v = sum[lane * (lane + 1) / 2 + j];
+        if (j == lane) v += 1.0;
+      }
+      row[j] = v;
+    }
+    const double tl = mine ? sum[kTrW * 16 + lane] : 0.0;
+    // Cholesky B = L L' (spectrum_loss.m:42), right-looking
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j < k) {  // wave-uniform
+        const double djj = __shfl(row[j], j);
+        pd = pd && (djj > 0.0);
+        const double ljj = sqrt(djj);
+        logdiag += log(ljj);
+        const double lij = lane == j ? ljj : row[j] / ljj;  // meaningful for lane >= j
+        row[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < KMAX; ++c) {
+          const double lcj = __shfl(lij, c);
+          if (lane >= c) row[c] = fma(-lij, lcj, row[c]);
+        }
+      }
+    }
+    if (mine) {
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j)
+        if (j < k) sL[lane * k + j] = j <= lane ? row[j] : 0.0;
+      st[lane] = tl;
+    }
+  }
+  __syncthreads();
+  if (real && pd) {
+    // column `lane` of L^-1: L x = e_lane (x_i = 0 for i < lane)
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      double r = 0.0;
+      if (i < k) {
+        r = i == lane ? 1.0 : 0.0;
+        double r2 = 0.0;  // two chains: the dot product is latency-, not throughput-bound
+#pragma unroll
+        for (int mm = 0; mm < i; ++mm) {  // broadcast reads
+          if (mm & 1) r2 = fma(-sL[i * k + mm], x[mm], r2);
+          else r = fma(-sL[i * k + mm], x[mm], r);
+        }
+        r = i >= lane ? (r + r2) / sL[i * k + i] : 0.0;
+      }
+      x[i] = r;
+    }
+  }
+  __syncthreads();  // every lane has read L: its storage now takes L^-1
+  if (real && pd && mine) {
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+      if (i < k) sL[i * k + lane] = x[i];
+  }
+  __syncthreads();
+  if (real && pd && mine) {  // B^-1 = L^-T L^-1: entry (lane, c) = Sum_i Linv[i][lane] Linv[i][c]
+    for (int c0 = 0; c0 < k; c0 += 4) {  // four columns at a time: independent chains
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i)
+        if (i < k) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) v[cc] = fma(x[i], sL[i * k + min(c0 + cc, k - 1)], v[cc]);
+        }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        if (c0 + cc < k) sBi[lane * k + c0 + cc] = v[cc];
+    }
+  }
+  __syncthreads();
+  if (real && pd && mine) {
+    double v = 0.0;
+    for (int c = 0; c < k; ++c) v = fma(sBi[lane * k + c], st[c], v);
+    sz[lane] = v;
+  }
+  __syncthreads();
+  const bool good = real && pd;
+  if (real && !pd && lane == 0) *a.not_pd = 1;
+  if (lane == 0) {
+    double v = 0.0;
+    if (good) {
+      double tz = 0.0;
+      for (int i = 0; i < k; ++i) tz = fma(st[i], sz[i], tz);
+      const double log_2pi = 1.83787706640934534;  // spectrum_loss.m:17
+      v = 0.5 * ((s_sc[wave][1] - tz) + s_sc[wave][0] + 2 * logdiag + s_sc[wave][2] * log_2pi);  // :48-52
+    }
+    a.nlogp[q] = v;  // (nlogp is allocated for the padded quasar count)
+  }
+  // T = B^-1 + z z' in the two operand tilings (zero for padded / failed quasars)
+  for (int e = lane; e < kTrCols; e += 64) {
+    double v = 0.0;
+    if (good) {
+      if (e < kTrW * 16) {
+        if (e < nb) v = sBi[s_vi[e] * k + s_vj[e]] + sz[s_vi[e]] * sz[s_vj[e]];
+      } else if (e - kTrW * 16 < k) {
+        v = sz[e - kTrW * 16];
+      }
+    }
+    s_outD[wave][e] = v;
+  }
+  for (int e = lane; e < kTrKs * 4; e += 64) {
+    const int ks = e >> 2, jj = e & 3;
+    double v = 0.0;
+    if (good) {
+      if (ks < kTrKsW) {
+        const int c = 4 * ks + jj;
+        if (c < nb) {
+          v = sBi[s_vi[c] * k + s_vj[c]] + sz[s_vi[c]] * sz[s_vj[c]];
+          if (s_vi[c] != s_vj[c]) v *= 2.0;  // m'T m = Sum_{i>=j} (2 - delta_ij) T_ij m_i m_j
+        }
+      } else {
+        const int c = 4 * (ks - kTrKsW) + jj;
+        if (c < k) v = sz[c];
+      }
+    }
+    s_outE[wave][e] = v;
+  }
+  __syncthreads();
+  // recD: [tq][16 tiles][jj = quasar % 4][col]: the block's 8 quasars are two whole quasar steps
+  for (int e = tid; e < 2 * kTrTiles * 64; e += kTrFQ * 64) {
+    const int tql = e / (kTrTiles * 64), r = e % (kTrTiles * 64);
+    const int c = r >> 6, jj = (r >> 4) & 3, col = r & 15;
+    a.recD[((q0 >> 2) + tql) * kTrTiles * 64 + r] = s_outD[4 * tql + jj][16 * c + col];
+  }
+  // recE: [g][58][jj = column % 4][s = quasar % 16]: 8 consecutive s per (ks, jj)
+  const int64_t g_blk = q0 >> 4;
+  const int s0 = (int)(q0 & 15);
+  for (int e = tid; e < kTrKs * 4 * kTrFQ; e += kTrFQ * 64) {
+    const int ql = e & (kTrFQ - 1), kj = e >> 3;  // kj = 4 ks + jj
+    a.recE[g_blk * kTrKs * 64 + (int64_t)kj * 16 + s0 + ql] = s_outE[ql][kj];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_train_core: one wave per (pixel group pt, split gs of the quasar groups).
+// X_qp = m_p' T_q m_p (53 column steps), Y_qp = m_p' z_q (5 column steps) by MFMA, then
+// core_qp and the sums over the wave's quasars: partcol[pt][gs][16] = Sum an core per pixel,
+// partsc[pt][gs][3] = Sum core da for (c0, tau0, beta).
+// ------------------------------------------------------------------------------------------
+struct TrainCoreArgs {
+  TrainDims d;
+  const double *recP, *recE;
+  const double *flux, *log_lya_1pz, *noise, *omega2;
+  double c_0, tau_0, beta;
+  double *partcol, *partsc;
+};
+constexpr size_t kTrCoreLds = 2 * kTrKs * 64 * sizeof(double);  // two quasar groups' A operands
+
+// A block is 4 waves = 4 pixel groups that walk the SAME quasar groups (split gs): the A operands
+// of a quasar group ([vech2(T_q) | z_q] of its 16 quasars, 29 KB) are staged once per block,
+// double-buffered by glds16; the B operands of the wave's pixel group stay in registers.
+__global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
+  extern __shared__ double smem[];
+  const TrainDims &D = a.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t pblk = blockIdx.x / D.GS;
+  const int gs = (int)(blockIdx.x % D.GS);
+  const int64_t pt = pblk * 4 + wave;
+  const bool active = pt < D.PG;
+  const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;  // balanced split
+  const int jj = lane >> 4, s = lane & 15;
+  const int64_t p = pt * 16 + s;
+  double bP[kTrKs];
+#pragma unroll
+  for (int ks = 0; ks < kTrKs; ++ks) bP[ks] = active ? a.recP[(pt * kTrKs + ks) * 64 + lane] : 0.0;
+  const double om = (active && p < D.G) ? a.omega2[p] : 0.0;
+  auto issue_group = [&](int64_t g) {
+    const int units = kTrKs * 32;  // 16-byte units
+    const double *src = a.recE + g * kTrKs * 64;
+    double *dst = smem + (size_t)((g - g0) & 1) * kTrKs * 64;
+    for (int i = wave; i * 64 < units; i += 4) {
+      const int unit = i * 64 + lane;
+      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)i * 128);
+    }
+  };
+  if (g0 < g1) issue_group(g0);
+  double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
+  for (int64_t g = g0; g < g1; ++g) {
+    glds_wait();
+    __syncthreads();
+    if (g + 1 < g1) issue_group(g + 1);
+    const double *re = smem + (size_t)((g - g0) & 1) * kTrKs * 64 + lane;
+    // two accumulator chains for X (registers: the kernel must stay within 256 per lane so that
+    // two waves share a SIMD), one for Y
+    d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, yv = x0;
+#pragma unroll
+    for (int ks = 0; ks < kTrKsW; ks += 2) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], x0, 0, 0, 0);
+      if (ks + 1 < kTrKsW) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 1) * 64], bP[ks + 1], x1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = kTrKsW; ks < kTrKs; ++ks)
+      yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], yv, 0, 0, 0);
+    double ye[4], lz[4], nv[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int64_t q = g * 16 + jj + 4 * rr;
+      const bool ok = active && q < D.nq && p < D.G;
+      ye[rr] = ok ? a.flux[q * D.G + p] : NAN;
+      lz[rr] = ok ? a.log_lya_1pz[q * D.G + p] : 0.0;
+      nv[rr] = ok ? a.noise[q * D.G + p] : 1.0;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {  // result register rr: quasar 16 g + jj + 4 rr, pixel p
+      const double y = ye[rr];
+      if (!isnan(y)) {
+        const double od = a.tau_0 * fast_rcp(exp_nonpos(-a.beta * lz[rr]));  // :22 (as k_train_prepare)
+        const double ab = exp_nonpos(-od);                        // :23
+        const double sf = 1 - ab + a.c_0;                         // :26
+        const double an = om * (sf * sf);                         // :27
+        const double w = fast_rcp(nv[rr] + an);                   // :29-31
+        const double u = w * y;
+        const double X = x0[rr] + x1[rr], Y = yv[rr];
+        const double kiy = u - w * Y;                             // (K^-1 y)_p, :46
+        const double diag = w - w * w * X + w * w * Y * Y;        // (K^-1)_pp = w - w^2 m'B^-1 m, :59
+        const double core = kiy * kiy - diag;
+        col = fma(an, core, col);                                 // :62
+        double da = a.c_0 * om * sf;                              // :65
+        gc = fma(core, da, gc);                                   // :66
+        da = om * sf * od * ab;                                   // :69
+        gt = fma(core, da, gt);                                   // :70
+        da = da * lz[rr] * a.beta;                                // :73
+        gb = fma(core, da, gb);                                   // :74
+      }
+    }
+  }
+  if (!active) return;
+  col += __shfl_xor(col, 16);
+  col += __shfl_xor(col, 32);
+  if (jj == 0) a.partcol[(pt * D.GS + gs) * 16 + s] = col;
+  for (int o = 32; o > 0; o >>= 1) {
+    gc += __shfl_xor(gc, o);
+    gt += __shfl_xor(gt, o);
+    gb += __shfl_xor(gb, o);
+  }
+  if (lane == 0) {
+    double *o3 = a.partsc + (pt * D.GS + gs) * 3;
+    o3[0] = gc;
+    o3[1] = gt;
+    o3[2] = gb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_train_finish: ordered sums.  Blocks 0 .. G-1: pixel p -> dM[p, :] and dlog_omega[p];
+// block G: f and the three scalar gradients.
+// ------------------------------------------------------------------------------------------
+struct TrainFinishArgs {
+  TrainDims d;
+  const double *M;
+  const double *partD;    // [PG][H2][16][256]
+  const double *partcol;  // [PG][GS][16]
+  const double *partsc;   // [PG][GS][3]
+  const double *nlogp;    // [16 NQ16]
+  const int32_t *flag_in; // not-PD flag of k_train_factor ...
+  double *flag_out;       // ... forwarded as a double next to f (one copy back to the host)
+  double *f, *g;          // g: [G (k+1) + 3]
+};
+
+__global__ __launch_bounds__(256) void k_train_finish(TrainFinishArgs a) {
+  __shared__ double s_a[kTrCols], s_red[256];
+  const TrainDims &D = a.d;
+  const int tid = threadIdx.x, k = D.k;
+  const int64_t G = D.G;
+  if ((int64_t)blockIdx.x < G) {
+    const int64_t p = blockIdx.x, pt = p >> 4;
+    const int ps = (int)(p & 15);
+    {  // A_p (vech) and C_p: sum of the quasar splits, in order
+      const double *pd = a.partD + ((pt * D.H2) * 16 + ps) * kTrCols + tid;
+      double v = 0.0;
+      for (int h = 0; h < D.H2; ++h) v += pd[(int64_t)h * 16 * kTrCols];
+      s_a[tid] = v;
+    }
+    __syncthreads();
+    if (tid < k) {  // dM[p, c] = Sum_e m_p[e] A_p[e, c] - C_p[c]   (:55-56)
+      double acc = 0.0;
+      for (int e = 0; e < k; ++e) {
+        const int i = e > tid ? e : tid, j = e > tid ? tid : e;
+        acc = fma(a.M[p + (int64_t)e * G], s_a[i * (i + 1) / 2 + j], acc);
+      }
+      a.g[p + (int64_t)tid * G] = acc - s_a[kTrW * 16 + tid];
+    }
+    if (tid == 64) {
+      double v = 0.0;
+      for (int gs = 0; gs < D.GS; ++gs) v += a.partcol[(pt * D.GS + gs) * 16 + ps];
+      a.g[G * k + p] = -v;  // :62
+    }
+    return;
+  }
+  // scalars: deterministic tree over a fixed assignment
+  for (int which = 0; which < 4; ++which) {
+    double v = 0.0;
+    if (which == 0) {
+      for (int64_t q = tid; q < D.nq; q += 256) v += a.nlogp[q];
+    } else {
+      for (int64_t e = tid; e < D.PG * D.GS; e += 256) v += a.partsc[e * 3 + (which - 1)];
+    }
+    s_red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) s_red[tid] += s_red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (which == 0) *a.flag_out = *a.flag_in ? 1.0 : 0.0;
+      if (which == 0) *a.f = s_red[0];
+      else a.g[G * (k + 1) + (which - 1)] = -s_red[0];  // :66, :70, :74
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace gpdla

@@ -70,3 +70,30 @@ def test_gpu_fit_decreases_objective():
     t.close()
     x1, f1, res = training.fit(x0, F, L1, NV, max_iter=30, max_fun_evals=60)
     assert f1 < f0 and np.isfinite(x1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_objective_is_deterministic_and_matches_the_atomic_kernel():
+    """The matrix-core path sums every partial in a fixed order: two evaluations agree bit for
+    bit (the one-block-per-quasar kernel it replaces for k <= 20 accumulated g with fp64 atomics).
+    Shapes that are not multiples of the 16-row / 4-step / 64-pixel tilings included."""
+    from gp_dla_detection_amd import training
+    for (nq, G, k) in ((37, 203, 20), (130, 70, 7), (5, 17, 2)):
+        x, F, L1, NV = training_problem(nq=nq, G=G, k=k, seed=100 + k)
+        t = training.TrainingSet(F, L1, NV)
+        f1, g1 = t.objective(x)
+        f2, g2 = t.objective(x)
+        t.close()
+        assert f1 == f2 and np.array_equal(g1, g2)
+        assert np.isfinite(g1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_objective_not_positive_definite_is_reported():
+    from gp_dla_detection_amd import _lib, training
+    x, F, L1, NV = training_problem(nq=20, G=48, k=4, seed=5)
+    NV = NV.copy()
+    NV[2] = -0.5  # negative variances make B = I + M'D^-1 M indefinite for that quasar (chol throws, :42)
+    with pytest.raises(_lib.GpdlaError) as e:
+        training.objective(x, F, L1, NV)
+    assert e.value.code == -4

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Times BASELINE config 4 (multi-DLA driver, S = 10000 samples, up to max_dlas stacked absorbers)
-through the one-shot entry point gpdla_process_batch_multi on one GPU.  Prints a JSON line."""
+on one GPU: the RESIDENT form (gpdla_batch_process_multi: spectra, profile table and every result
+stay in HBM; what a multi-GPU run would shard) and, for reference, the one-shot host-buffer entry
+point (PCIe-inclusive).  An "evaluation" is one low-rank log-likelihood: per quasar
+S x (1 sub-DLA + max_dlas DLA models).  Prints a JSON line."""
 import argparse
 import json
 import os
@@ -15,25 +18,48 @@ from gp_dla_detection_amd import synthetic  # noqa: E402
 from gp_dla_detection_amd.parameters import MultiParameters  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--spectra", type=int, default=32)
+ap.add_argument("--spectra", type=int, default=64)
 ap.add_argument("--pixels", type=int, default=1500)
 ap.add_argument("--samples", type=int, default=10000)
 ap.add_argument("--max-dlas", type=int, default=4)
+ap.add_argument("--k", type=int, default=20)
+ap.add_argument("--steps", type=int, default=3)
 args = ap.parse_args()
 p = MultiParameters(max_dlas=args.max_dlas)
-model = synthetic.make_model(20)
+model = synthetic.make_model(args.k)
 samples = synthetic.make_samples(args.samples)
 base = synthetic.make_spectra(min(8, args.spectra), args.pixels, model, first_index=500)
 spectra = [base[i % len(base)] for i in range(args.spectra)]
 cat = synthetic.make_prior_catalog()
 z = np.array([s["z_qso"] for s in spectra])
 lp = gp.dla_existence_prior_multi(cat["z_qsos"], cat["dla_ind"], z, 0.31, 0.69, p)
-gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra[:2], tuple(x[:2] for x in lp), params=p)
-t0 = time.perf_counter()
-out = gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=p)
-dt = time.perf_counter() - t0
 evals = args.spectra * args.samples * (1 + args.max_dlas)  # LLS + max_dlas DLA models
-print(json.dumps({"metric": "multi-DLA sample log-likelihoods/sec (host buffers in/out)",
-                  "value": evals / dt, "seconds": dt, "spectra": args.spectra, "pixels": args.pixels,
-                  "samples": args.samples, "max_dlas": args.max_dlas,
-                  "evaluations": evals, "finite_fraction": float(np.isfinite(out["sample_log_likelihoods_dla"]).mean())}))
+
+ctx = gp.Context(0, p)
+ctx.set_model(model)
+ctx.set_samples(samples)
+batch = ctx.upload(spectra, lp[0], lp[2], lp[1])
+batch.process_multi()  # warm-up: allocates the result tables and the profile table
+ctx.synchronize()
+ctx.set_timing(True)
+ms = []
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    batch.process_multi()
+    ms.append(ctx.last_sweep_ms())  # hipEvents around the whole pipeline of one call
+ctx.synchronize()
+wall = (time.perf_counter() - t0) / args.steps
+out = batch.download_multi()
+batch.close()
+ctx.close()
+
+t0 = time.perf_counter()
+gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=p)
+pcie = time.perf_counter() - t0
+flops = evals * (args.pixels * args.k * (args.k + 3) + args.k ** 3 / 3.0)
+print(json.dumps({"metric": "multi-DLA sample log-likelihoods/sec (resident in HBM)",
+                  "value": evals / wall, "gpu_ms_per_call": float(np.mean(ms)), "wall_ms_per_call": wall * 1e3,
+                  "algorithmic_tflops": flops / (np.mean(ms) * 1e-3) / 1e12,
+                  "pcie_inclusive_value": evals / pcie, "spectra": args.spectra, "pixels": args.pixels,
+                  "samples": args.samples, "max_dlas": args.max_dlas, "k": args.k, "evaluations": evals,
+                  "finite_fraction": float(np.isfinite(out["sample_log_likelihoods_dla"]).mean())}))
