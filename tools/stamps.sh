@@ -2,6 +2,7 @@
 # Diagnostic: build the sweep kernel with s_memtime stamps (-DGPDLA_STAMP) and print where a wave's
 # cycles go, segment by segment (run on the GPU box).  Shares only: the stamps forbid overlaps.
 set -e
+set -o pipefail
 cd "$(dirname "$0")/.."
 SRC=gp_dla_detection_amd/csrc/gpdla.hip
 FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -Wno-inline-asm"
