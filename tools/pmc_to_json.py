@@ -18,18 +18,23 @@ def main():
     workload = sys.argv[3] if len(sys.argv) > 3 else "configs1"
     # bench.py's own line from one of the counter passes says what shape was run
     bench = {}
-    for log in sorted(glob.glob(os.path.join(out, f"pmc_{tag}_*.log"))):
-        try:
-            bench = json.loads(open(log).read().strip().splitlines()[-1])
+    for log in sorted(glob.glob(os.path.join(out, f"pmc_{tag}_[A-Z]*.log"))):
+        for line in open(log).read().splitlines():  # (rocprofv3's own messages share the log)
+            if line.startswith('{"metric"'):
+                try:
+                    bench = json.loads(line)
+                except ValueError:
+                    pass
+        if bench:
             break
-        except (ValueError, IndexError):
-            continue
     cfg = bench.get("config", {})
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "gp_dla_detection_amd", "csrc", "libgpdla.so"), "rb") as f:
         sha = hashlib.sha256(f.read()).hexdigest()
     counters, launches, kernel = {}, {}, None
-    for path in glob.glob(os.path.join(out, f"pmc_{tag}_*", "**", "*counter_collection.csv"), recursive=True):
+    # pass directories are pmc_<tag>_<COUNTER GROUP>: a longer tag that merely starts with this one
+    # (r02 vs r02_mix) continues in lower case, a counter group in upper case
+    for path in glob.glob(os.path.join(out, f"pmc_{tag}_[A-Z]*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
                 if "k_sweep" not in row["Kernel_Name"]:
