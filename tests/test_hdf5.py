@@ -247,3 +247,39 @@ def test_cross_read_with_h5py_when_available(tmp_path):
         assert f["matrix"].attrs["MATLAB_class"] == b"double"
         first = f[f["ragged"][0, 0]]
         np.testing.assert_array_equal(first[()].ravel(), want["ragged"][0])
+
+
+def test_random_round_trips_hypothesis(tmp_path_factory):
+    """Property test of the writer against the reader: random dtypes, ranks 1-3, extents that do
+    and do not divide the chunk extents, contiguous / chunked / chunked+deflate(+shuffle)."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+    dtypes = st.sampled_from(["<f8", "<f4", "<i1", "<i2", "<i4", "<i8", "<u1", "<u2", "<u4", "<u8"])
+    base = tmp_path_factory.mktemp("hyp")
+    counter = [0]
+
+    @settings(max_examples=40, deadline=None, derandomize=True)
+    @given(data=st.data(), dtype=dtypes, shape=hnp.array_shapes(min_dims=1, max_dims=3, min_side=1, max_side=9),
+           mode=st.sampled_from(["contiguous", "chunked", "gzip", "gzip+shuffle"]))
+    def run(data, dtype, shape, mode):
+        arr = data.draw(hnp.arrays(dtype, shape, elements=(st.floats(-1e6, 1e6, width=32) if dtype[1] == "f"
+                                                            else st.integers(0, 100))))
+        counter[0] += 1
+        p = str(base / f"h{counter[0]}.h5")
+        w = hdf5.FileWriter(p)
+        if mode == "contiguous":
+            w.create_dataset("a", arr, attrs={"note": "x", "n": np.int32(7)})
+        else:
+            chunks = tuple(data.draw(st.integers(1, s)) for s in shape)
+            w.create_dataset("a", arr, chunks=chunks, compression="gzip" if mode.startswith("gzip") else None,
+                             shuffle=mode.endswith("shuffle"), attrs={"note": "x", "n": np.int32(7)})
+        w.close()
+        with hdf5.File(p) as f:
+            d = f["a"]
+            assert d.shape == arr.shape and d.dtype == arr.dtype
+            np.testing.assert_array_equal(d.read(), arr)
+            assert d.attrs["note"] == "x" and d.attrs["n"] == 7
+            assert f.eof == os.path.getsize(p)
+
+    run()
