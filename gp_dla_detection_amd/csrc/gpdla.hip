@@ -790,30 +790,30 @@ int gpdla_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M
   if (k > 256) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d too large", k);
   int rc = select_device(device_id);
   if (rc) return rc;
+  // one packed upload (y | mu | d | M), one packed download (log_p | status)
   double *buf = nullptr;
-  int *d_status = nullptr;
   const size_t nn = (size_t)n, ws = (size_t)k * (k + 1) / 2 + k + 2;
-  const size_t total = 3 * nn + nn * k + ws + 1;
+  const size_t n_in = 3 * nn + nn * k, total = n_in + ws + 2;
   if ((rc = dev_alloc(&buf, total))) return rc;
-  if ((rc = dev_alloc(&d_status, 1))) {
-    dev_free(buf);
-    return rc;
-  }
+  std::vector<double> host(n_in);
+  std::memcpy(host.data(), y, nn * sizeof(double));
+  std::memcpy(host.data() + nn, mu, nn * sizeof(double));
+  std::memcpy(host.data() + 2 * nn, d, nn * sizeof(double));
+  std::memcpy(host.data() + 3 * nn, M, nn * k * sizeof(double));
   double *dy = buf, *dmu = dy + nn, *dd = dmu + nn, *dM = dd + nn, *dws = dM + nn * k, *dlp = dws + ws;
-  hipError_t e = hipMemcpy(dy, y, nn * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dmu, mu, nn * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dd, d, nn * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dM, M, nn * k * sizeof(double), hipMemcpyHostToDevice);
-  int status = 0;
+  int *d_status = reinterpret_cast<int *>(dlp + 1);
+  hipError_t e = hipMemcpy(buf, host.data(), n_in * sizeof(double), hipMemcpyHostToDevice);
+  double back[2] = {NAN, 0.0};
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_lowrank_single, dim3(1), dim3(256), 0, 0, dy, dmu, dM, dd, n, k, dws, dlp, d_status);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpy(log_p, dlp, sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(back, dlp, 2 * sizeof(double), hipMemcpyDeviceToHost);
   dev_free(buf);
-  dev_free(d_status);
   if (e != hipSuccess) return fail(GPDLA_ERR_HIP, "gpdla_log_mvnpdf_low_rank: %s", hipGetErrorString(e));
+  int status;
+  std::memcpy(&status, &back[1], sizeof(int));
+  *log_p = back[0];
   if (status) {
     *log_p = NAN;
     return fail(GPDLA_ERR_NOT_POSITIVE_DEFINITE, "B = I + M' D^-1 M is not positive definite");

@@ -1412,31 +1412,45 @@ __global__ __launch_bounds__(256) void k_lowrank_single(const double *y, const d
   ld = sh[0] + sh[1] + sh[2] + sh[3];
   __threadfence_block();
   __syncthreads();
+  // Cholesky of the packed lower triangle, column by column: the pivot by thread 0, the column
+  // below it by all threads (left-looking), then z = L^-1 v (log_mvnpdf_low_rank.m:24-28)
+  __shared__ double s_piv;
+  __shared__ int s_pd;
+  if (tid == 0) s_pd = 1;
+  double *v = ws + nb;
+  for (int j = 0; j < k; ++j) {
+    const int rj = j * (j + 1) / 2;
+    __syncthreads();
+    if (tid == 0) {
+      double sum = ws[rj + j];
+      for (int mm = 0; mm < j; ++mm) sum = fma(-ws[rj + mm], ws[rj + mm], sum);
+      if (!(sum > 0.0)) s_pd = 0;
+      const double ljj = sqrt(sum);
+      ws[rj + j] = ljj;
+      s_piv = ljj;
+    }
+    __syncthreads();
+    const double ljj = s_piv;
+    for (int i = j + 1 + tid; i < k; i += 256) {
+      const int ri = i * (i + 1) / 2;
+      double sum = ws[ri + j];
+      for (int mm = 0; mm < j; ++mm) sum = fma(-ws[ri + mm], ws[rj + mm], sum);
+      ws[ri + j] = sum / ljj;
+    }
+  }
+  __syncthreads();
   if (tid == 0) {
-    double *v = ws + nb;
     double log_diag = 0.0, zz = 0.0;
-    bool pd = true;
     for (int i = 0; i < k; ++i) {
       const int ri = i * (i + 1) / 2;
-      for (int j = 0; j <= i; ++j) {
-        const int rj = j * (j + 1) / 2;
-        double sum = ws[ri + j];
-        for (int mm = 0; mm < j; ++mm) sum = fma(-ws[ri + mm], ws[rj + mm], sum);
-        if (i == j) {
-          pd = pd && (sum > 0.0);
-          const double lii = sqrt(sum);
-          log_diag += log(lii);
-          ws[ri + j] = lii;
-        } else {
-          ws[ri + j] = sum / ws[rj + j];
-        }
-      }
+      log_diag += log(ws[ri + i]);
       double zi = v[i];
       for (int mm = 0; mm < i; ++mm) zi = fma(-ws[ri + mm], v[mm], zi);
       zi /= ws[ri + i];
       v[i] = zi;
       zz = fma(zi, zi, zz);
     }
+    const bool pd = s_pd != 0;
     *log_p = pd ? -0.5 * ((qs - zz) + ld + 2 * log_diag + (double)n * kLog2Pi) : NAN;
     *status = pd ? 0 : 1;
   }

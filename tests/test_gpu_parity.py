@@ -104,6 +104,23 @@ def test_sweep_against_exact_arithmetic(golden, model20):
     assert d.max() < TOL, d.max()
 
 
+def test_log_mvnpdf_ranks_beyond_the_sweep_limit(oracle):
+    """The MATLAB function takes any k; the stand-alone surface accepts k <= 256 (only the batch
+    sweep is limited to GPDLA_MAX_K = 40)."""
+    rng = np.random.default_rng(21)
+    for n, k in ((300, 64), (500, 129), (260, 256)):
+        M = rng.standard_normal((n, k)) * 0.2
+        mu = rng.standard_normal(n)
+        d = 10.0 ** rng.uniform(-2, 0, n)
+        y = mu + M @ rng.standard_normal(k) + np.sqrt(d) * rng.standard_normal(n)
+        want, rc = oracle.log_mvnpdf_low_rank(y, mu, M, d)
+        assert rc == 0
+        assert abs(gp.log_mvnpdf_low_rank(y, mu, M, d) - want) < 1e-9 * max(1.0, abs(want)), (n, k)
+    with pytest.raises(_lib.GpdlaError) as e:
+        gp.log_mvnpdf_low_rank(np.zeros(4), np.zeros(4), np.zeros((4, 257)), np.ones(4))
+    assert e.value.code == -5
+
+
 def test_log_mvnpdf_not_positive_definite():
     n, k = 6, 2
     with pytest.raises(_lib.GpdlaError) as e:
