@@ -943,13 +943,14 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
     pa.offset_samples = c->d_offset;
     pa.nhi_samples = c->d_nhi;
     pa.lls_nhi_samples = c->d_lls_nhi;
+    pa.perm = c->d_perm;
     pa.S = S;
     pa.num_lines = c->cfg.num_lines;
     pa.q0 = q0;
     pa.nq_sub = nsub;
     pa.stride = stride;
     pa.prof = mb.prof;
-    const int64_t waves = (int64_t)nsub * 2 * S;
+    const int64_t waves = (int64_t)nsub * 2 * ((S + 63) / 64);
     hipLaunchKernelGGL(k_profiles, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, pa);
     HIP_TRY(hipGetLastError());
     for (int mode = 1; mode <= md; ++mode) {

@@ -20,14 +20,20 @@
 namespace gpdla {
 
 // ------------------------------------------------------------------------------------------
-// k_profiles: one wave per (quasar, kind, sample); lanes run along 64 padded pixels, the 7-tap
-// broadening comes from wave shuffles, 58 outputs per pass.
+// k_profiles: one LANE per profile (quasar, kind, sample); a wave holds 64 samples that are
+// neighbours in z_DLA (perm order), walks the padded pixels in lockstep -- the padded wavelength is
+// a wave-uniform load, the accurate Voigt tier is taken by whole waves -- and keeps the seven raw
+// values the instrument broadening needs (voigt.c:297-299) in registers: no cross-lane traffic
+// and no idle lanes (the round-1 form, one wave per profile with lanes along the pixels, paid 12
+// ds_bpermute per value and idled 6 of 64 lanes).  Outputs are transposed through LDS, 16 pixels
+// at a time, so that every store instruction writes whole 128-byte pieces of profile rows.
 // prof[((ql * 2 + kind) * S + i) * stride + p], p < stride (>= 4 * steps; entries >= n_u are 1).
 // ------------------------------------------------------------------------------------------
 struct ProfilesArgs {
   const QuasarMeta *meta;
   const double *lam_pad;
   const double *offset_samples, *nhi_samples, *lls_nhi_samples;
+  const int32_t *perm;   // [S] sample indices in ascending offset (= z_DLA) order
   int64_t S;
   int32_t num_lines;
   int64_t q0;        // first quasar of this sub-batch
@@ -36,44 +42,54 @@ struct ProfilesArgs {
   double *prof;
 };
 
+constexpr int kProfTile = 16;  // pixels per transposed store
+
 __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
-  __shared__ double s_mult[4][kMaxLines];
   __shared__ double s_exp[kExpTab];  // 2^(j/64), the table behind exp_table()
+  __shared__ double s_out[4][64][kProfTile + 1];
+
   if (threadIdx.x < kExpTab) s_exp[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / kExpTab));
   __syncthreads();  // (before any wave may leave)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t wpk = (a.S + 63) / 64;                     // waves per (quasar, kind)
   const int64_t w_global = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t per_q = 2 * a.S;
-  const int64_t ql = w_global / per_q;
+  const int64_t ql = w_global / (2 * wpk);
   if (ql >= a.nq_sub) return;
-  const int64_t rem = w_global - ql * per_q;
-  const int kind = (int)(rem / a.S);
-  const int64_t i = rem - (int64_t)kind * a.S;
+  const int64_t rem = w_global - ql * 2 * wpk;
+  const int kind = (int)(rem / wpk);
+  const int64_t pos0 = (rem - (int64_t)kind * wpk) * 64;
   const QuasarMeta m = a.meta[a.q0 + ql];
-  double *row = a.prof + ((ql * 2 + kind) * a.S + i) * a.stride;
   if (m.status != 0) return;
   const int L = a.num_lines;
+  const bool live = pos0 + lane < a.S;
+  const int64_t i = a.perm[live ? pos0 + lane : a.S - 1];
   const double z_dla = m.min_z_dla + (m.max_z_dla - m.min_z_dla) * a.offset_samples[i];  // multi :309
   const double nhi = kind ? a.lls_nhi_samples[i] : a.nhi_samples[i];
-  if (lane < L) s_mult[wave][lane] = g_lines.c / (g_lines.wavelength_cm[lane] * (1 + z_dla)) / 1e8;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
+  double mult[3], ms[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    mult[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;  // voigt.c:278-279
+    ms[j] = mult[j] * inv_s;
+  }
+  const double cs = c_light * inv_s;
+  const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
   const double *lam = a.lam_pad + m.lam_off;
   const int n_pad = m.n_u + 6;
-  const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
-  const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
-  const int nseg = (m.n_u + 57) / 58;
-  for (int seg = 0; seg < nseg; ++seg) {
-    const int P = seg * 58 + lane;
-    const double lamP = lam[min(P, n_pad - 1)];
+  double *rows = a.prof + ((ql * 2 + kind) * a.S) * a.stride;  // + i * stride + p
+  const double t0 = g_lines.taps[0], t1 = g_lines.taps[1], t2 = g_lines.taps[2], t3 = g_lines.taps[3],
+               t4 = g_lines.taps[4], t5 = g_lines.taps[5], t6 = g_lines.taps[6];
+
+  auto raw_at = [&](int P) -> double {  // voigt.c:282-292 for this lane's sample at padded pixel P
+    const double lamP = lam[min(P, n_pad - 1)];  // wave-uniform address
     double total = 0.0;
     bool near = false;
-    if (L == 3) {  // the driver's case: the sweep kernel's merged three-line wing tier
-      total = wing_sum3(lamP, s_mult[wave][0] * inv_s, s_mult[wave][1] * inv_s, s_mult[wave][2] * inv_s,
-                        c_light * inv_s, &near);
+    if (L == 3) {
+      total = wing_sum3(lamP, ms[0], ms[1], ms[2], cs, &near);
     } else {
       for (int j = 0; j < L; ++j) {
-        const double x = (lamP * s_mult[wave][j] - c_light) * inv_s;  // voigt.c:287
+        const double mj = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
+        const double x = (lamP * mj - c_light) * inv_s;  // voigt.c:287
         const double x2 = x * x;
         near |= x2 < 900.0;
         total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
@@ -82,20 +98,53 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
     if (__any(near)) {  // accurate tier: per-line piecewise polynomials (near_tables.hpp), as in k_sweep
       total = 0.0;
       for (int j = 0; j < L; ++j) {
-        const double ax = fabs((lamP * s_mult[wave][j] - c_light) * inv_s);
+        const double mj = j < 3 ? mult[j] : g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
+        const double ax = fabs((lamP * mj - c_light) * inv_s);
         total += ax < 30.0 ? 1.7724538509055159 * g_lines.leading[j] *
                                  near_poly(g_lines.near_poly + j * kNearLineDoubles, ax)
                            : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
       }
     }
-    const double raw = exp_table(nscale * total, s_exp);  // voigt.c:291
-    double acc = raw * g_lines.taps[0];             // voigt.c:297-299
+    return exp_table(nscale * total, s_exp);  // voigt.c:291
+  };
+
+  // window of raw values P .. P+6 for output pixel P (the profile of pixel p uses padded p .. p+6)
+  double r0 = raw_at(0), r1 = raw_at(1), r2 = raw_at(2), r3 = raw_at(3), r4 = raw_at(4), r5 = raw_at(5), r6;
+  const int64_t nrows = min((int64_t)64, a.S - pos0);
+  for (int p0 = 0; p0 < m.n_u; p0 += kProfTile) {
 #pragma unroll
-    for (int kk = 1; kk < 7; ++kk) acc = fma(__shfl_down(raw, kk), g_lines.taps[kk], acc);
-    const int p = seg * 58 + lane;
-    if (lane < 58 && p < m.n_u) row[p] = acc;
+    for (int tt = 0; tt < kProfTile; ++tt) {
+      r6 = raw_at(p0 + tt + 6);
+      double acc = r0 * t0;  // voigt.c:297-299, taps in ascending order
+      acc = fma(r1, t1, acc);
+      acc = fma(r2, t2, acc);
+      acc = fma(r3, t3, acc);
+      acc = fma(r4, t4, acc);
+      acc = fma(r5, t5, acc);
+      acc = fma(r6, t6, acc);
+      s_out[wave][lane][tt] = acc;
+      r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // transposed store: instruction e writes pixels p0 .. p0+15 of rows 4e .. 4e+3
+    const int tt = lane & 15;
+#pragma unroll 4
+    for (int e = 0; e < 16; ++e) {
+      const int rl = 4 * e + (lane >> 4);
+      if (rl < nrows && p0 + tt < m.n_u) {
+        const int64_t ir = a.perm[pos0 + rl];
+        rows[ir * a.stride + p0 + tt] = s_out[wave][rl][tt];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-  for (int64_t p = m.n_u + lane; p < a.stride; p += 64) row[p] = 1.0;
+  // padding behind the pixels: 1 (no absorption)
+  for (int64_t rl = 0; rl < nrows; ++rl) {
+    const int64_t ir = a.perm[pos0 + rl];
+    for (int64_t p = m.n_u + lane; p < a.stride; p += 64) rows[ir * a.stride + p] = 1.0;
+  }
+
 }
 
 // ------------------------------------------------------------------------------------------
