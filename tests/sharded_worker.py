@@ -66,3 +66,39 @@ def run_rank(rank, world, port, kind, out_dir, num_quasars):
     finally:
         if world > 1:
             dist.destroy_process_group()
+
+
+def run_rccl_world1(port, out_dir):
+    """RCCL itself cannot be given two ranks on one GPU (it refuses duplicate devices), so on a
+    one-GPU box the RCCL leg is exercised at world size 1: backend "nccl" is initialised and its
+    all-gather runs on the library-owned summary table exactly as bench.py / distributed.py hand
+    it over -- a zero-copy torch view of HBM that libgpdla.so allocated."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch
+    import torch.distributed as dist
+
+    import gp_dla_detection_amd as gp
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        model, samples, spectra, lp, _ = build_case("single")
+        stream = torch.cuda.Stream()
+        ctx = gp.Context(0, stream=stream)
+        ctx.set_model(model)
+        ctx.set_samples(samples)
+        batch = ctx.upload(spectra, lp[0], lp[1])
+        with torch.cuda.stream(stream):
+            batch.process()
+            table = batch.summary_tensor()
+            out = torch.empty_like(table)
+            dist.all_gather_into_tensor(out, table)       # RCCL reads the library's buffer in place
+            total = table[:, 5].clone()
+            dist.all_reduce(total, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        ref = batch.download()
+        np.savez(os.path.join(out_dir, "rccl_w1.npz"), gathered=out.cpu().numpy(), table=table.cpu().numpy(),
+                 ll=ref["log_likelihoods_dla"], backend=np.array(dist.get_backend()))
+        batch.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()

@@ -99,3 +99,21 @@ def test_world_2_with_fewer_quasars_than_ranks(tmp_path):
     ranks = run_world(2, "single", tmp_path, 1)
     check("single", ranks, unsharded("single", 1), 1)
     assert [tuple(int(x) for x in r["block"]) for r in ranks] == [(0, 1), (1, 1)]
+
+
+def test_rccl_backend_gathers_the_library_owned_table(tmp_path):
+    """The RCCL leg at world size 1 (see sharded_worker.run_rccl_world1): backend nccl initialises
+    on the box and all-gathers the zero-copy summary tensor on the sweep's own stream."""
+    ctx = mp.get_context("forkserver")
+    pr = ctx.Process(target=sharded_worker.run_rccl_world1, args=(free_port(), str(tmp_path)))
+    pr.start()
+    pr.join(600)
+    if pr.is_alive():
+        pr.kill()
+        pr.join()
+    assert pr.exitcode == 0
+    res = np.load(tmp_path / "rccl_w1.npz")
+    assert str(res["backend"]) == "nccl"
+    np.testing.assert_array_equal(res["gathered"], res["table"])
+    np.testing.assert_array_equal(res["table"][:, 5], res["ll"])
+    assert res["table"].shape == (7, 15)
