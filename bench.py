@@ -25,7 +25,6 @@ import hashlib
 import json
 import math
 import os
-import re
 import sys
 import time
 

@@ -126,7 +126,7 @@ def _world():
     return 1, 0
 
 
-def _block(spectra, pixel_counts, lo, hi):
+def _block(spectra, lo, hi):
     """This rank's spectra: a slice of the full list, or whatever the loader returns for [lo, hi)."""
     if callable(spectra):
         block = list(spectra(lo, hi))
@@ -187,7 +187,7 @@ def process_qsos_sharded(model, samples, spectra, log_priors, params=None, devic
         try:
             ctx.set_model(model)
             ctx.set_samples(samples)
-            batch = ctx.upload(_block(spectra, pixel_counts, lo, hi), lp_no[lo:hi], lp_dla[lo:hi])
+            batch = ctx.upload(_block(spectra, lo, hi), lp_no[lo:hi], lp_dla[lo:hi])
             try:
                 batch.process()
                 ctx.synchronize()
@@ -233,7 +233,7 @@ def process_qsos_multiple_dlas_meanflux_sharded(model, samples, spectra, log_pri
         try:
             ctx.set_model(model)
             ctx.set_samples(samples)
-            batch = ctx.upload(_block(spectra, pixel_counts, lo, hi), lp_no[lo:hi], lp_dla[lo:hi],
+            batch = ctx.upload(_block(spectra, lo, hi), lp_no[lo:hi], lp_dla[lo:hi],
                                lp_lls[lo:hi])
             try:
                 batch.process_multi(None if base_sample_inds is None else

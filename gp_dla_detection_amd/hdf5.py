@@ -161,8 +161,7 @@ class File:
             pos = sb + 24 + (4 if version == 1 else 0)
             self.stored_base, _, self.eof, _ = struct.unpack_from("<4Q", mm, pos)
             pos += 32
-            _, root_header, cache, _ = struct.unpack_from("<QQII", mm, pos)
-            self._root_addr = root_header
+            _, self._root_addr, _, _ = struct.unpack_from("<QQII", mm, pos)  # (cache type: not relied on)
         elif version in (2, 3):
             so, sl = mm[sb + 9], mm[sb + 10]
             if (so, sl) != (8, 8):

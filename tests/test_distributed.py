@@ -2,7 +2,6 @@
 world_size 2 (the same code path RCCL runs on the GPUs; only the backend differs)."""
 import os
 import socket
-import sys
 
 import numpy as np
 import pytest

@@ -1,8 +1,7 @@
 """Round trips of the .mat readers/writers: v5 files through scipy, -v7.3 (HDF5) files through the
 package's own HDF5 implementation (tests/test_hdf5.py tests that layer by itself)."""
 import numpy as np
-import pytest
-from scipy.io import loadmat, savemat
+from scipy.io import savemat
 
 from gp_dla_detection_amd import io, synthetic
 

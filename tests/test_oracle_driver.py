@@ -5,7 +5,6 @@ frozen golden outputs (catches accidental edits), (2) against an independent Num
 written with different primitives (np.interp, scipy wofz, dense K), (3) through properties.
 """
 import numpy as np
-import pytest
 from scipy.special import wofz
 
 from gp_dla_detection_amd import _lyman, synthetic
