@@ -1156,6 +1156,12 @@ struct gpdla_training {
   int ws_k = 0;
   double *h_stage = nullptr;  // pinned host staging for x (in) and [g | f | flag] (out)
   int64_t stage_capacity = 0;
+  // one evaluation = H2D of x, nine kernels, D2H of [g | f | flag]: captured once per k into a
+  // hipGraph and replayed (no kernel argument changes between evaluations)
+  hipStream_t stream = nullptr;
+  hipGraphExec_t graph = nullptr;
+  int graph_k = 0;
+  double *d_scal = nullptr;
   double *d_wA = nullptr, *d_uA = nullptr, *d_wB = nullptr, *d_uB = nullptr, *d_part1 = nullptr;
   double *d_recM = nullptr, *d_recP = nullptr, *d_partB = nullptr, *d_recD = nullptr, *d_recE = nullptr;
   double *d_nlogp = nullptr, *d_partD = nullptr, *d_partcol = nullptr, *d_partsc = nullptr;
@@ -1174,6 +1180,9 @@ void gpdla_training_destroy(gpdla_training *t) {
                   (void *)t->d_partD, (void *)t->d_partcol, (void *)t->d_partsc})
     dev_free(p);
   if (t->h_stage) (void)hipHostFree(t->h_stage);
+  if (t->graph) (void)hipGraphExecDestroy(t->graph);
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  dev_free(t->d_scal);
   delete t;
 }
 
@@ -1238,10 +1247,99 @@ TrainDims train_dims(const gpdla_training *t, int k) {
   return d;
 }
 
-// objective.m:12-75 on the matrix cores (k <= 20): value and gradient, deterministic.
-int training_objective_mfma(gpdla_training *t, const double *x, int k, double *f, double *g) {
+// One evaluation of objective.m:12-75 on the matrix cores (k <= 20), enqueued on `st`: H2D of x
+// from the pinned staging buffer, the kernels, D2H of [g | f | flag] into it.
+int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   const TrainDims d = train_dims(t, k);
-  const int64_t G = t->G;
+  const int64_t G = t->G, nx = G * (k + 1) + 3;
+  HIP_TRY(hipMemcpyAsync(t->d_x, t->h_stage, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(t->d_flag, 0, sizeof(int32_t), st));
+  TrainScalarsArgs sc;
+  sc.x = t->d_x;
+  sc.G = G;
+  sc.k = k;
+  sc.omega2 = t->d_omega2;
+  sc.scal = t->d_scal;
+  hipLaunchKernelGGL(k_train_scalars, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, sc);
+  TrainPrepareArgs pa;
+  pa.d = d;
+  pa.flux = t->d_flux;
+  pa.log_lya_1pz = t->d_loglya;
+  pa.noise = t->d_noise;
+  pa.omega2 = t->d_omega2;
+  pa.scal = t->d_scal;
+  pa.wA = t->d_wA;
+  pa.uA = t->d_uA;
+  pa.wB = t->d_wB;
+  pa.uB = t->d_uB;
+  pa.part1 = t->d_part1;
+  hipLaunchKernelGGL(k_train_prepare, dim3((unsigned)(d.NQ16 * d.PB)), dim3(256), 0, st, pa);
+  TrainRecordsArgs ra;
+  ra.d = d;
+  ra.M = t->d_x;
+  ra.recM = t->d_recM;
+  ra.recP = t->d_recP;
+  hipLaunchKernelGGL(k_train_records, dim3(1024), dim3(256), 0, st, ra);
+  TrainContractArgs ca;  // B_q, t_q: rows = quasars, steps over pixels
+  ca.Aw = t->d_wA;
+  ca.Au = t->d_uA;
+  ca.Brec = t->d_recM;
+  ca.R = d.NQ16;
+  ca.steps = d.T;
+  ca.nsplit = d.H;
+  ca.out = t->d_partB;
+  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
+  TrainFactorArgs fa;
+  fa.d = d;
+  fa.partB = t->d_partB;
+  fa.part1 = t->d_part1;
+  fa.recD = t->d_recD;
+  fa.recE = t->d_recE;
+  fa.nlogp = t->d_nlogp;
+  fa.not_pd = t->d_flag;
+  hipLaunchKernelGGL(k_train_factor<20>, dim3((unsigned)(d.NQ16 * 16 / kTrFQ)), dim3(kTrFQ * 64), 0, st, fa);
+  ca.Aw = t->d_wB;  // dM: rows = pixels, steps over quasars
+  ca.Au = t->d_uB;
+  ca.Brec = t->d_recD;
+  ca.R = d.PG;
+  ca.steps = d.TQ;
+  ca.nsplit = d.H2;
+  ca.out = t->d_partD;
+  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.PG + kTrCWaves - 1) / kTrCWaves) * d.H2)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
+  TrainCoreArgs co;
+  co.d = d;
+  co.recP = t->d_recP;
+  co.recE = t->d_recE;
+  co.flux = t->d_flux;
+  co.log_lya_1pz = t->d_loglya;
+  co.noise = t->d_noise;
+  co.omega2 = t->d_omega2;
+  co.scal = t->d_scal;
+  co.partcol = t->d_partcol;
+  co.partsc = t->d_partsc;
+  hipLaunchKernelGGL(k_train_core, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), kTrCoreLds, st, co);
+  TrainFinishArgs fi;
+  fi.d = d;
+  fi.M = t->d_x;
+  fi.partD = t->d_partD;
+  fi.partcol = t->d_partcol;
+  fi.partsc = t->d_partsc;
+  fi.nlogp = t->d_nlogp;
+  fi.f = t->d_g + nx;        // f and the not-PD flag ride behind g: one copy back
+  fi.flag_in = t->d_flag;
+  fi.flag_out = t->d_g + nx + 1;
+  fi.scal = t->d_scal;
+  fi.g = t->d_g;
+  hipLaunchKernelGGL(k_train_finish, dim3((unsigned)(G + 1)), dim3(256), 0, st, fi);
+  HIP_TRY(hipMemcpyAsync(t->h_stage, t->d_g, (size_t)(nx + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+  return GPDLA_OK;
+}
+
+// objective.m:12-75 on the matrix cores (k <= 20): value and gradient, deterministic.  x is in the
+// pinned staging buffer on entry; [g | f | flag] is there on return.
+int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
+  const TrainDims d = train_dims(t, k);
+  const int64_t G = t->G, nx = G * (k + 1) + 3;
   int rc;
   if (!t->d_wA) {
     const size_t tiled = (size_t)d.NQ16 * d.T * 64;
@@ -1253,92 +1351,34 @@ int training_objective_mfma(gpdla_training *t, const double *x, int k, double *f
         (rc = dev_alloc(&t->d_recD, (size_t)d.TQ * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recE, (size_t)d.NQ16 * kTrKs * 64)) ||
         (rc = dev_alloc(&t->d_nlogp, (size_t)d.NQ16 * 16)) ||
         (rc = dev_alloc(&t->d_partD, (size_t)d.PG * d.H2 * 16 * kTrCols)) ||
-        (rc = dev_alloc(&t->d_partcol, (size_t)d.PG * d.GS * 16)) || (rc = dev_alloc(&t->d_partsc, (size_t)d.PG * d.GS * 3)))
+        (rc = dev_alloc(&t->d_partcol, (size_t)d.PG * d.GS * 16)) || (rc = dev_alloc(&t->d_partsc, (size_t)d.PG * d.GS * 3)) ||
+        (rc = dev_alloc(&t->d_scal, 3)))
       return rc;
+    HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_contract),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrContractLds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_core),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrCoreLds));
   }
-  const double c_0 = std::exp(x[G * (k + 1)]), tau_0 = std::exp(x[G * (k + 1) + 1]), beta = std::exp(x[G * (k + 1) + 2]);
-  HIP_TRY(hipMemsetAsync(t->d_flag, 0, sizeof(int32_t), 0));
-  hipLaunchKernelGGL(k_training_omega2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, 0, t->d_x + G * k, G, t->d_omega2);
-  TrainPrepareArgs pa;
-  pa.d = d;
-  pa.flux = t->d_flux;
-  pa.log_lya_1pz = t->d_loglya;
-  pa.noise = t->d_noise;
-  pa.omega2 = t->d_omega2;
-  pa.c_0 = c_0;
-  pa.tau_0 = tau_0;
-  pa.beta = beta;
-  pa.wA = t->d_wA;
-  pa.uA = t->d_uA;
-  pa.wB = t->d_wB;
-  pa.uB = t->d_uB;
-  pa.part1 = t->d_part1;
-  hipLaunchKernelGGL(k_train_prepare, dim3((unsigned)(d.NQ16 * d.PB)), dim3(256), 0, 0, pa);
-  TrainRecordsArgs ra;
-  ra.d = d;
-  ra.M = t->d_x;
-  ra.recM = t->d_recM;
-  ra.recP = t->d_recP;
-  hipLaunchKernelGGL(k_train_records, dim3(1024), dim3(256), 0, 0, ra);
-  TrainContractArgs ca;  // B_q, t_q: rows = quasars, steps over pixels
-  ca.Aw = t->d_wA;
-  ca.Au = t->d_uA;
-  ca.Brec = t->d_recM;
-  ca.R = d.NQ16;
-  ca.steps = d.T;
-  ca.nsplit = d.H;
-  ca.out = t->d_partB;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_contract),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrContractLds));
-  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H)), dim3(kTrCWaves * 64), kTrContractLds, 0, ca);
-  TrainFactorArgs fa;
-  fa.d = d;
-  fa.partB = t->d_partB;
-  fa.part1 = t->d_part1;
-  fa.recD = t->d_recD;
-  fa.recE = t->d_recE;
-  fa.nlogp = t->d_nlogp;
-  fa.not_pd = t->d_flag;
-  hipLaunchKernelGGL(k_train_factor<20>, dim3((unsigned)(d.NQ16 * 16 / kTrFQ)), dim3(kTrFQ * 64), 0, 0, fa);
-  ca.Aw = t->d_wB;  // dM: rows = pixels, steps over quasars
-  ca.Au = t->d_uB;
-  ca.Brec = t->d_recD;
-  ca.R = d.PG;
-  ca.steps = d.TQ;
-  ca.nsplit = d.H2;
-  ca.out = t->d_partD;
-  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.PG + kTrCWaves - 1) / kTrCWaves) * d.H2)), dim3(kTrCWaves * 64), kTrContractLds, 0, ca);
-  TrainCoreArgs co;
-  co.d = d;
-  co.recP = t->d_recP;
-  co.recE = t->d_recE;
-  co.flux = t->d_flux;
-  co.log_lya_1pz = t->d_loglya;
-  co.noise = t->d_noise;
-  co.omega2 = t->d_omega2;
-  co.c_0 = c_0;
-  co.tau_0 = tau_0;
-  co.beta = beta;
-  co.partcol = t->d_partcol;
-  co.partsc = t->d_partsc;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_core),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrCoreLds));
-  hipLaunchKernelGGL(k_train_core, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), kTrCoreLds, 0, co);
-  TrainFinishArgs fi;
-  fi.d = d;
-  fi.M = t->d_x;
-  fi.partD = t->d_partD;
-  fi.partcol = t->d_partcol;
-  fi.partsc = t->d_partsc;
-  fi.nlogp = t->d_nlogp;
-  const int64_t nx = G * (k + 1) + 3;
-  fi.f = t->d_g + nx;        // f and the not-PD flag ride behind g: one copy back
-  fi.flag_in = t->d_flag;
-  fi.flag_out = t->d_g + nx + 1;
-  fi.g = t->d_g;
-  hipLaunchKernelGGL(k_train_finish, dim3((unsigned)(G + 1)), dim3(256), 0, 0, fi);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(t->h_stage, t->d_g, (size_t)(nx + 2) * sizeof(double), hipMemcpyDeviceToHost));
+  if (!t->graph || t->graph_k != k) {  // capture the evaluation once per k
+    if (t->graph) (void)hipGraphExecDestroy(t->graph);
+    t->graph = nullptr;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
+    rc = training_enqueue_mfma(t, k, t->stream);
+    hipError_t e = hipStreamEndCapture(t->stream, &graph);
+    if (rc) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    if (e != hipSuccess) return fail(GPDLA_ERR_HIP, "training graph capture failed: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&t->graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(GPDLA_ERR_HIP, "training graph instantiation failed: %s", hipGetErrorString(e));
+    t->graph_k = k;
+  }
+  HIP_TRY(hipGraphLaunch(t->graph, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
   std::memcpy(g, t->h_stage, (size_t)nx * sizeof(double));
   *f = t->h_stage[nx];
   if (t->h_stage[nx + 1] != 0.0)
@@ -1367,21 +1407,13 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
     t->h_stage = nullptr;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&t->h_stage), (size_t)(nx + 2) * sizeof(double), hipHostMallocDefault));
   }
-  std::memcpy(t->h_stage, x, (size_t)nx * sizeof(double));
-  HIP_TRY(hipMemcpyAsync(t->d_x, t->h_stage, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, 0));
-  // k <= 20: the three contractions on the matrix cores, ordered (deterministic) sums.
-  // GPDLA_TRAIN_LEGACY=1 (diagnostic) or k > 20: one block per quasar, fp64 atomics into g.
+  // k <= 20: the three contractions on the matrix cores, ordered (deterministic) sums, one graph
+  // launch per evaluation.  GPDLA_TRAIN_LEGACY=1 (diagnostic) or k > 20: one block per quasar,
+  // fp64 atomics into g.
   static const bool legacy = std::getenv("GPDLA_TRAIN_LEGACY") != nullptr;
-  if (k <= 20 && !legacy) {
-    if (t->ws_k == 0) t->ws_k = k;
-    int rc = training_objective_mfma(t, x, k, f, g);
-    if (rc) return rc;
-    const double tau_0 = std::exp(x[G * (k + 1) + 1]), beta = std::exp(x[G * (k + 1) + 2]);
-    const double tau_0_mu = 0.0023, tau_0_sigma = 0.0007, beta_mu = 3.65, beta_sigma = 0.21;  // objective.m:59-71
-    g[G * (k + 1) + 1] += tau_0 * (tau_0 - tau_0_mu) / (tau_0_sigma * tau_0_sigma);
-    g[G * (k + 1) + 2] += beta * (beta - beta_mu) / (beta_sigma * beta_sigma);
-    return GPDLA_OK;
-  }
+  std::memcpy(t->h_stage, x, (size_t)nx * sizeof(double));
+  if (k <= 20 && !legacy) return training_objective_mfma(t, k, f, g);
+  HIP_TRY(hipMemcpy(t->d_x, t->h_stage, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(t->d_g, 0, (size_t)nx * sizeof(double)));
   HIP_TRY(hipMemset(t->d_f, 0, sizeof(double)));
   HIP_TRY(hipMemset(t->d_flag, 0, sizeof(int32_t)));

@@ -68,7 +68,7 @@ struct TrainPrepareArgs {
   TrainDims d;
   const double *flux, *log_lya_1pz, *noise;  // [nq][G], NaN flux = missing pixel (objective.m:42)
   const double *omega2;                      // [G]
-  double c_0, tau_0, beta;
+  const double *scal;                        // [3] c0, tau0, beta (k_train_scalars: exp of the last three x)
   double *wA, *uA, *wB, *uB, *part1;
 };
 
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void k_train_prepare(TrainPrepareArgs a) {
   const int64_t g = blockIdx.x / D.PB, pb = blockIdx.x % D.PB;
   const int tid = threadIdx.x, pl = tid & 63, wv = tid >> 6;
   const int64_t p = pb * 64 + pl;
+  const double c_0 = a.scal[0], tau_0 = a.scal[1], beta = a.scal[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int ql = wv + 4 * i;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_train_prepare(TrainPrepareArgs a) {
       const double y = a.flux[q * D.G + p];
       if (!isnan(y)) {
         double d;
-        train_element(y, a.log_lya_1pz[q * D.G + p], a.noise[q * D.G + p], a.omega2[p], a.c_0, a.tau_0, a.beta,
+        train_element(y, a.log_lya_1pz[q * D.G + p], a.noise[q * D.G + p], a.omega2[p], c_0, tau_0, beta,
                       &w, &u, &d);
         logd = log(d);
         yy = y * u;
@@ -496,7 +497,7 @@ struct TrainCoreArgs {
   TrainDims d;
   const double *recP, *recE;
   const double *flux, *log_lya_1pz, *noise, *omega2;
-  double c_0, tau_0, beta;
+  const double *scal;  // [3] c0, tau0, beta
   double *partcol, *partsc;
 };
 constexpr size_t kTrCoreLds = 2 * kTrKs * 64 * sizeof(double);  // two quasar groups' A operands
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;  // balanced split
   const int jj = lane >> 4, s = lane & 15;
   const int64_t p = pt * 16 + s;
+  const double c_0 = a.scal[0], tau_0 = a.scal[1], beta = a.scal[2];
   double bP[kTrKs];
 #pragma unroll
   for (int ks = 0; ks < kTrKs; ++ks) bP[ks] = active ? a.recP[(pt * kTrKs + ks) * 64 + lane] : 0.0;
@@ -559,9 +561,9 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
     for (int rr = 0; rr < 4; ++rr) {  // result register rr: quasar 16 g + jj + 4 rr, pixel p
       const double y = ye[rr];
       if (!isnan(y)) {
-        const double od = a.tau_0 * fast_rcp(exp_nonpos(-a.beta * lz[rr]));  // :22 (as k_train_prepare)
+        const double od = tau_0 * fast_rcp(exp_nonpos(-beta * lz[rr]));  // :22 (as k_train_prepare)
         const double ab = exp_nonpos(-od);                        // :23
-        const double sf = 1 - ab + a.c_0;                         // :26
+        const double sf = 1 - ab + c_0;                           // :26
         const double an = om * (sf * sf);                         // :27
         const double w = fast_rcp(nv[rr] + an);                   // :29-31
         const double u = w * y;
@@ -570,11 +572,11 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
         const double diag = w - w * w * X + w * w * Y * Y;        // (K^-1)_pp = w - w^2 m'B^-1 m, :59
         const double core = kiy * kiy - diag;
         col = fma(an, core, col);                                 // :62
-        double da = a.c_0 * om * sf;                              // :65
+        double da = c_0 * om * sf;                                // :65
         gc = fma(core, da, gc);                                   // :66
         da = om * sf * od * ab;                                   // :69
         gt = fma(core, da, gt);                                   // :70
-        da = da * lz[rr] * a.beta;                                // :73
+        da = da * lz[rr] * beta;                                  // :73
         gb = fma(core, da, gb);                                   // :74
       }
     }
@@ -596,6 +598,21 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   }
 }
 
+// exp of the three scalar parameters (objective.m:30-32) and omega2 = exp(2 log omega) (:29): on
+// the device, so that no kernel argument changes between evaluations and the whole evaluation
+// replays as one captured graph
+struct TrainScalarsArgs {
+  const double *x;   // [G (k+1) + 3]
+  int64_t G;
+  int32_t k;
+  double *omega2, *scal;
+};
+__global__ void k_train_scalars(TrainScalarsArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < a.G) a.omega2[p] = exp(2 * a.x[a.G * a.k + p]);
+  if (p < 3) a.scal[p] = exp(a.x[a.G * (a.k + 1) + p]);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_train_finish: ordered sums.  Blocks 0 .. G-1: pixel p -> dM[p, :] and dlog_omega[p];
 // block G: f and the three scalar gradients.
@@ -609,6 +626,7 @@ struct TrainFinishArgs {
   const double *nlogp;    // [16 NQ16]
   const int32_t *flag_in; // not-PD flag of k_train_factor ...
   double *flag_out;       // ... forwarded as a double next to f (one copy back to the host)
+  const double *scal;     // [3] c0, tau0, beta: the Kim et al. priors enter the gradient (objective.m:59-71)
   double *f, *g;          // g: [G (k+1) + 3]
 };
 
@@ -658,8 +676,15 @@ __global__ __launch_bounds__(256) void k_train_finish(TrainFinishArgs a) {
     }
     if (tid == 0) {
       if (which == 0) *a.flag_out = *a.flag_in ? 1.0 : 0.0;
-      if (which == 0) *a.f = s_red[0];
-      else a.g[G * (k + 1) + (which - 1)] = -s_red[0];  // :66, :70, :74
+      if (which == 0) {
+        *a.f = s_red[0];
+      } else {
+        double v = -s_red[0];  // :66, :70, :74
+        const double tau_0_mu = 0.0023, tau_0_sigma = 0.0007, beta_mu = 3.65, beta_sigma = 0.21;  // objective.m:59-71
+        if (which == 2) v += a.scal[1] * (a.scal[1] - tau_0_mu) / (tau_0_sigma * tau_0_sigma);
+        if (which == 3) v += a.scal[2] * (a.scal[2] - beta_mu) / (beta_sigma * beta_sigma);
+        a.g[G * (k + 1) + (which - 1)] = v;
+      }
     }
     __syncthreads();
   }
