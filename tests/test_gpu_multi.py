@@ -143,3 +143,22 @@ def test_empty_quasar_is_flagged(oracle):
     assert np.isnan(out["model_posteriors"][0]).all()
     ref = oracle_multi(oracle, model, samples, good, out["base_sample_inds"][1], p)
     compare(out, 1, ref, p)
+
+
+def test_randomised_multi_shapes_vs_oracle(oracle):
+    """Seeded fuzz of the multi-DLA driver: max_dlas 1..4, rank 3..40, 60..400 pixels, 16..120
+    samples, masks; indices drawn on the GPU and replayed by the oracle."""
+    rng = np.random.default_rng(11)
+    for trial in range(8):
+        md = int(rng.integers(1, 5))
+        k = int(rng.choice([3, 12, 20, 20, 27, 40]))
+        n = int(rng.integers(60, 400))
+        S = int(rng.integers(16, 120))
+        p = MultiParameters(max_dlas=md, rng_seed=1000 + trial)
+        model = synthetic.make_model(k)
+        samples = synthetic.make_samples(S)
+        sp = synthetic.make_spectrum(3000 + trial, n, model, mask_fraction=float(rng.uniform(0, 0.1)))
+        out = gp.process_qsos_multiple_dlas_meanflux(model, samples, [sp], priors([sp], p), params=p)
+        bsi = out["base_sample_inds"][0] if md > 1 else np.zeros((0, S), np.uint32)
+        ref = oracle_multi(oracle, model, samples, sp, bsi, p)
+        compare(out, 0, ref, p)

@@ -418,3 +418,30 @@ def test_chunked_driver_matches_single_batch(model20):
     many = gp.process_qsos(model20, samples, spectra, log_priors=lp, max_quasars_per_batch=3)
     for key in ("sample_log_likelihoods_dla", "log_likelihoods_dla", "model_posteriors", "status"):
         np.testing.assert_array_equal(one[key], many[key])
+
+
+def test_randomised_shapes_vs_oracle(oracle):
+    """Seeded fuzz over the sweep's shape space: rank 1..40 (all three kernel classes), 30..700
+    pixels, 1..90 samples, 0..20 % masked, 1 / 3 / 5 lines -- every log-likelihood against the
+    oracle at 1e-8."""
+    from oracle.oracle import OracleParams
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for trial in range(24):
+        k = int(rng.integers(1, 41))
+        n = int(rng.integers(30, 700))
+        S = int(rng.integers(1, 90))
+        nl = int(rng.choice([3, 3, 1, 5]))
+        model = synthetic.make_model(k)
+        samples = synthetic.make_samples(S)
+        sp = synthetic.make_spectrum(2000 + trial, n, model, mask_fraction=float(rng.uniform(0, 0.2)))
+        out = gp.process_qsos(model, samples, [sp], log_priors=flat_priors(1), params=gp.Parameters(num_lines=nl))
+        ref = oracle.process_spectrum(model, samples["offset_samples"], samples["nhi_samples"], sp["wavelengths"],
+                                      sp["flux"], sp["noise_variance"], sp["pixel_mask"], sp["z_qso"],
+                                      params=OracleParams(num_lines=nl))
+        d = max(float(np.nanmax(np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]))),
+                abs(out["log_likelihoods_no_dla"][0] - ref["log_likelihood_no_dla"]),
+                abs(out["log_likelihoods_dla"][0] - ref["log_likelihood_dla"]))
+        assert d < TOL, (trial, k, n, S, nl, d)
+        worst = max(worst, d)
+    print(f"fuzz: worst |delta| over 24 random shapes = {worst:.2e}")
