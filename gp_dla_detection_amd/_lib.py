@@ -30,6 +30,10 @@ _u8p = C.POINTER(C.c_uint8)
 _u32p = C.POINTER(C.c_uint32)
 
 
+# gpdla_status (include/gpdla.h)
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSITIVE_DEFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+
+
 class GpdlaError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"libgpdla error {code}: {message}")
