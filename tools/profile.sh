@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- \
   python3 $ROOT/bench.py --workload $WORKLOAD --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $OUT/prof_$TAG.log 2>&1
 cp $(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1) $OUT/profiles/${TAG}_kernel_stats.csv
-tail -1 $OUT/prof_$TAG.log > $OUT/profiles/${TAG}_bench_under_rocprof.json
+grep "^{\"metric\"" $OUT/prof_$TAG.log | tail -1 > $OUT/profiles/${TAG}_bench_under_rocprof.json
 # one derived TCC counter per pass (FETCH_SIZE + WRITE_SIZE together exceed the hardware's counters)
 for group in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" \
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
