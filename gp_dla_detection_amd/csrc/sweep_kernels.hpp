@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
 //   [+16, +20)       padded wavelengths 4(t+3) .. 4(t+3)+3 (the raw profile runs three steps ahead)
 // Record `steps` (one past the last K-step) is neutral: zero tiles, (y, mu, omega2, nu) = (0,0,0,1).
 //   [+20, +32)       unused (keeps records 16-byte granular and 256-byte aligned)
-// compact class only (record_extras == 48):
+// compact class only (record_extras == 64, the last 16 unused):
 //   [+24, +32)       vech columns 208, 209 of pixels 4t .. 4t+3 (pixel jj at +24 + 2 jj)
 //   [+32, +48)       m columns 16 .. 19 of pixels 4t .. 4t+3   (pixel jj at +32 + 4 jj)
 // ------------------------------------------------------------------------------------------
@@ -330,7 +330,8 @@ struct BuildRecordsArgs {
 constexpr int kCompactTiles = 14, kXW = 2, kXU = 4, kXWColumn = 208, kXUColumn = 16;
 __host__ __device__ constexpr bool tiles_compact(int ntiles) { return ntiles == kCompactTiles; }
 // doubles of per-step extras behind the tiles of a record
-__host__ __device__ constexpr int record_extras(int ntiles) { return tiles_compact(ntiles) ? 48 : 32; }
+// (compact: 48 used, padded to 64 so that a record is a whole number of 512-byte tiles)
+__host__ __device__ constexpr int record_extras(int ntiles) { return tiles_compact(ntiles) ? 64 : 32; }
 // tiles' worth of columns a sample's [vech(B) | v] occupies in the epilogue's LDS rows
 __host__ __device__ constexpr int logical_tiles(int ntiles) { return tiles_compact(ntiles) ? 16 : ntiles; }
 // doubles per record: tiles (64 elements each, as double or float) + the extras
@@ -952,11 +953,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   const int s = lane & 15, jj = lane >> 4;
   const int L = LINES > 0 ? LINES : a.num_lines;
 
-  double *exp_tab = smem;                                          // [64] at LDS address 0: its index
-                                                                   // needs no base add in the K-loop
+  // LDS addressing costs VALU instructions (which cost MFMA time, fact 1 of DESIGN.md section 4)
+  // whenever a constant does not fit the instruction's offset field: 8 bits x 8 B for
+  // ds_read2_b64, 8 bits x 512 B for ds_read2st64_b64, 16 bits for ds_read_b64 / ds_read_b128.  So:
+  // the ring, read with ds_read2_b64, sits at address 0 (a lane's 37 slots fit the 2040 B reach);
+  // the exp table and the records' extras are read with b64 / b128; records are a multiple of
+  // 512 B and the stage buffers 512-B aligned, so the tile reads fold (buffer, step, tile) into
+  // the st64 offsets.
+  double *ring = smem;                                             // [WAVES][16][33]
+  double *exp_tab = ring + WAVES * kSamplesPerWave * kRing2;       // [64]
   double *stage = exp_tab + kExpTab;                               // [2][kChunkSteps][RD]
-  double *ring = stage + (size_t)2 * kChunkSteps * RD;             // [WAVES][16][33]
-  double *mult_s = ring + WAVES * kSamplesPerWave * kRing2;        // [GROUPS*16][L]
+  double *mult_s = stage + (size_t)2 * kChunkSteps * RD;           // [GROUPS*16][L]
 
   const int64_t slot0 = (int64_t)bq * (GROUPS * kSamplesPerWave) + group * kSamplesPerWave;
   const int64_t slot = slot0 + s;
@@ -1089,8 +1096,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         // operands of the broadening / weights / MFMAs of this step
         const double *g = my_ring + slot_p;
         const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4], g5 = g[5], g6 = g[6];
-        const double py = extra[4 * jj], pmu = extra[4 * jj + 1], pom = extra[4 * jj + 2],
-                     pnu = extra[4 * jj + 3];
+        const double2 p01 = *reinterpret_cast<const double2 *>(extra + 4 * jj);  // ds_read_b128
+        const double2 p23 = *reinterpret_cast<const double2 *>(extra + 4 * jj + 2);
+        const double py = p01.x, pmu = p01.y, pom = p23.x, pnu = p23.y;
         __builtin_amdgcn_sched_barrier(0);  // keep the reads up here (the scheduler sinks them)
         // (1) raw profile three K-steps ahead: voigt.c:282-292
         double total;
@@ -1187,11 +1195,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         }
 #endif
         if (kCompact) {  // vech columns 208, 209 and m columns 16..19 of this lane's pixel: 6 FMAs
-          const double *xp = extra + 24 + 2 * jj, *up = extra + 32 + 4 * jj;
-#pragma unroll
-          for (int x = 0; x < kXW; ++x) xw[x] = fma(w, xp[x], xw[x]);
-#pragma unroll
-          for (int x = 0; x < kXU; ++x) xu[x] = fma(u, up[x], xu[x]);
+          static_assert(kXW == 2 && kXU == 4, "three 16-byte reads");
+          const double2 xp = *reinterpret_cast<const double2 *>(extra + 24 + 2 * jj);
+          const double2 u01 = *reinterpret_cast<const double2 *>(extra + 32 + 4 * jj);
+          const double2 u23 = *reinterpret_cast<const double2 *>(extra + 32 + 4 * jj + 2);
+          xw[0] = fma(w, xp.x, xw[0]);
+          xw[1] = fma(w, xp.y, xw[1]);
+          xu[0] = fma(u, u01.x, xu[0]);
+          xu[1] = fma(u, u01.y, xu[1]);
+          xu[2] = fma(u, u23.x, xu[2]);
+          xu[3] = fma(u, u23.y, xu[3]);
         }
         GPDLA_ST(3)  // MFMA burst (issue)
       }
@@ -1228,7 +1241,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #undef GPDLA_RAW_ACCURATE
   // ---- epilogue: factor_pass over the MFMA result registers ------------------------------------
   using ES = EpilogueShape<TW, TS>;
-  double *Eg = stage + (size_t)group * ES::SPP * ES::stride(logical_tiles(NT));  // [SPP samples][stride] of this group
+  double *Eg = smem + kExpTab + (size_t)group * ES::SPP * ES::stride(logical_tiles(NT));  // [SPP samples][stride] of this group
 #pragma unroll
   for (int p = 0; p < ES::PASSES; ++p) {
     int sigma;
