@@ -252,13 +252,13 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
 #define GPDLA_MPREP(rec, absorb_in)                                                       \
   {                                                                                       \
     const double *extra_ = (rec) + NT * 64;                                               \
+    const double *mine_ = extra_ + extras_row(NT, 1) * jj;                                \
     if (kCompact) {                                                                       \
-      _Pragma("unroll") for (int x = 0; x < kXW; ++x) xpr[x] = extra_[24 + 2 * jj + x];   \
-      _Pragma("unroll") for (int x = 0; x < kXU; ++x) upr[x] = extra_[32 + 4 * jj + x];   \
+      _Pragma("unroll") for (int x = 0; x < kXW; ++x) xpr[x] = mine_[kExtrasXW + x];      \
+      _Pragma("unroll") for (int x = 0; x < kXU; ++x) upr[x] = mine_[kExtrasXU + x];      \
     }                                                                                     \
     const double absorb_ = (absorb_in);                                                   \
-    const double py_ = extra_[4 * jj], pmu_ = extra_[4 * jj + 1], pom_ = extra_[4 * jj + 2], \
-                 pnu_ = extra_[4 * jj + 3];                                               \
+    const double py_ = mine_[0], pmu_ = mine_[1], pom_ = mine_[2], pnu_ = mine_[3];       \
     const double r_ = fma(-absorb_, pmu_, py_);      /* multi :355 */                     \
     const double a2_ = absorb_ * absorb_;                                                 \
     const double d_ = fma(pom_, a2_, pnu_);          /* multi :357, :361 */               \

@@ -307,9 +307,13 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
 //   [+16, +20)       padded wavelengths 4(t+3) .. 4(t+3)+3 (the raw profile runs three steps ahead)
 // Record `steps` (one past the last K-step) is neutral: zero tiles, (y, mu, omega2, nu) = (0,0,0,1).
 //   [+20, +32)       unused (keeps records 16-byte granular and 256-byte aligned)
-// compact class only (record_extras == 64, the last 16 unused):
-//   [+24, +32)       vech columns 208, 209 of pixels 4t .. 4t+3 (pixel jj at +24 + 2 jj)
-//   [+32, +48)       m columns 16 .. 19 of pixels 4t .. 4t+3   (pixel jj at +32 + 4 jj)
+// compact class (record_extras == 64) instead: one 16-double block per pixel jj at +16 jj, so that
+// a lane of the sweep reaches all of its operands from ONE address (see k_sweep on LDS offsets):
+//   +0 .. +3   PixelRow (y, mu, omega2, nu) of pixel 4t + jj
+//   +4 .. +7   m columns 16 .. 19 of that pixel
+//   +8, +9     vech columns 208, 209 of that pixel
+//   +10        padded wavelength 4(t+3) + jj
+//   +11 .. +15 unused
 // ------------------------------------------------------------------------------------------
 struct BuildRecordsArgs {
   const QuasarMeta *meta;
@@ -330,8 +334,14 @@ struct BuildRecordsArgs {
 constexpr int kCompactTiles = 14, kXW = 2, kXU = 4, kXWColumn = 208, kXUColumn = 16;
 __host__ __device__ constexpr bool tiles_compact(int ntiles) { return ntiles == kCompactTiles; }
 // doubles of per-step extras behind the tiles of a record
-// (compact: 48 used, padded to 64 so that a record is a whole number of 512-byte tiles)
+// (compact: 4 x 11 used of 64, which also makes a record a whole number of 512-byte tiles)
 __host__ __device__ constexpr int record_extras(int ntiles) { return tiles_compact(ntiles) ? 64 : 32; }
+// offsets into the extras of pixel jj's PixelRow and of its padded wavelength; compact class: of
+// its m columns 16..19 and vech columns 208, 209 relative to the PixelRow
+__host__ __device__ constexpr int extras_row(int ntiles, int jj) { return tiles_compact(ntiles) ? 16 * jj : 4 * jj; }
+__host__ __device__ constexpr int extras_lam(int ntiles, int jj) { return tiles_compact(ntiles) ? 16 * jj + 10 : 16 + jj; }
+__host__ __device__ constexpr int extras_lam_stride(int ntiles) { return extras_lam(ntiles, 1) - extras_lam(ntiles, 0); }
+constexpr int kExtrasXU = 4, kExtrasXW = 8;
 // tiles' worth of columns a sample's [vech(B) | v] occupies in the epilogue's LDS rows
 __host__ __device__ constexpr int logical_tiles(int ntiles) { return tiles_compact(ntiles) ? 16 : ntiles; }
 // doubles per record: tiles (64 elements each, as double or float) + the extras
@@ -398,23 +408,36 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
       const int ls = e / xtra, r2 = e - ls * xtra;
       const int step = step0 + ls;
       double v = 0.0;
-      if (r2 < 16) {
-        const PixelRow px = a.pix[m.pix_off + 4 * (int64_t)step + (r2 >> 2)];
-        const int f = r2 & 3;
-        v = f == 0 ? px.y : f == 1 ? px.mu : f == 2 ? px.omega2 : px.nu;
+      // (pixel, field): field 0..3 PixelRow, 4 wavelength, 5..8 m columns 16.., 9, 10 vech 208, 209
+      int jj = -1, f = 0;
+      if (xtra > 32) {  // compact class: per-pixel blocks
+        const int o = r2 & 15;
+        jj = r2 >> 4;
+        f = o < 4 ? o : o < 4 + kXU ? 5 + (o - 4) : o < 4 + kXU + kXW ? 9 + (o - 4 - kXU) : o == 10 ? 4 : -1;
+        static_assert(kExtrasXU == 4 && kExtrasXW == 4 + kXU && 4 + kXU + kXW == 10, "block layout");
+      } else if (r2 < 16) {
+        jj = r2 >> 2;
+        f = r2 & 3;
       } else if (r2 < 20) {
-        int P = 4 * (step + 3) + (r2 - 16);
-        if (P > n_pad - 1) P = n_pad - 1;
-        v = a.lam_pad[m.lam_off + P];
-      } else if (r2 >= 24 && xtra > 32) {  // compact class: the columns kept off the matrix cores
-        const bool is_w = r2 < 32;
-        const int jj = is_w ? (r2 - 24) >> 1 : (r2 - 32) >> 2;
-        const int x = is_w ? (r2 - 24) & 1 : (r2 - 32) & 3;
-        const double *row = s_rows[ls * 4 + jj];
-        if (is_w) {  // vech index 208 + x = (19, 18 + x)
-          if (kXWColumn + x < ncol_w) v = row[19] * row[18 + x];
-        } else if (kXUColumn + x < k) {
-          v = row[kXUColumn + x];
+        jj = r2 - 16;
+        f = 4;
+      }
+      if (jj >= 0 && f >= 0) {
+        if (f < 4) {
+          const PixelRow px = a.pix[m.pix_off + 4 * (int64_t)step + jj];
+          v = f == 0 ? px.y : f == 1 ? px.mu : f == 2 ? px.omega2 : px.nu;
+        } else if (f == 4) {
+          int P = 4 * (step + 3) + jj;
+          if (P > n_pad - 1) P = n_pad - 1;
+          v = a.lam_pad[m.lam_off + P];
+        } else {  // compact class: the columns kept off the matrix cores
+          const double *row = s_rows[ls * 4 + jj];
+          if (f >= 9) {  // vech index 208 + x = (19, 18 + x)
+            const int x = f - 9;
+            if (kXWColumn + x < ncol_w) v = row[19] * row[18 + x];
+          } else if (kXUColumn + (f - 5) < k) {
+            v = row[kXUColumn + (f - 5)];
+          }
         }
       }
       out[(int64_t)step * RD + RD - xtra + r2] = v;
@@ -1092,12 +1115,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         // (s_waitcnt lgkmcnt(0), free) lets the raw chain start under the 15 reads issued next
         // instead of behind all of them.
         if (tt > 0) __builtin_amdgcn_s_waitcnt(0xC07F);
-        const double lamP = tt == 0 ? extra[16 + jj] : lam_next;
+        const double *mine = extra + extras_row(NT, 1) * jj;  // this lane's pixel
+        const double lamP = tt == 0 ? extra[extras_lam_stride(NT) * jj + extras_lam(NT, 0)] : lam_next;
         // operands of the broadening / weights / MFMAs of this step
         const double *g = my_ring + slot_p;
         const double g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4], g5 = g[5], g6 = g[6];
-        const double2 p01 = *reinterpret_cast<const double2 *>(extra + 4 * jj);  // ds_read_b128
-        const double2 p23 = *reinterpret_cast<const double2 *>(extra + 4 * jj + 2);
+        const double2 p01 = *reinterpret_cast<const double2 *>(mine);  // ds_read_b128
+        const double2 p23 = *reinterpret_cast<const double2 *>(mine + 2);
         const double py = p01.x, pmu = p01.y, pom = p23.x, pnu = p23.y;
         __builtin_amdgcn_sched_barrier(0);  // keep the reads up here (the scheduler sinks them)
         // (1) raw profile three K-steps ahead: voigt.c:282-292
@@ -1171,7 +1195,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         }
         // next step's wavelength, in flight during the MFMA burst
         if (tt + 1 < kChunkSteps) {
-          lam_next = extra[RD + 16 + jj];
+          lam_next = extra[RD + extras_lam_stride(NT) * jj + extras_lam(NT, 0)];
           __builtin_amdgcn_sched_barrier(0);
         }
         GPDLA_ST(2)  // fragments, ring, broadening, weights
@@ -1196,9 +1220,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #endif
         if (kCompact) {  // vech columns 208, 209 and m columns 16..19 of this lane's pixel: 6 FMAs
           static_assert(kXW == 2 && kXU == 4, "three 16-byte reads");
-          const double2 xp = *reinterpret_cast<const double2 *>(extra + 24 + 2 * jj);
-          const double2 u01 = *reinterpret_cast<const double2 *>(extra + 32 + 4 * jj);
-          const double2 u23 = *reinterpret_cast<const double2 *>(extra + 32 + 4 * jj + 2);
+          const double2 xp = *reinterpret_cast<const double2 *>(mine + kExtrasXW);
+          const double2 u01 = *reinterpret_cast<const double2 *>(mine + kExtrasXU);
+          const double2 u23 = *reinterpret_cast<const double2 *>(mine + kExtrasXU + 2);
           xw[0] = fma(w, xp.x, xw[0]);
           xw[1] = fma(w, xp.y, xw[1]);
           xu[0] = fma(u, u01.x, xu[0]);
