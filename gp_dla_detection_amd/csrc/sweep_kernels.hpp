@@ -884,9 +884,12 @@ __device__ __forceinline__ ExpState exp_table_begin(double x, const double *tab)
   return e;
 }
 __device__ __forceinline__ double exp_table_end(const ExpState &e) {
-  double p = 0.008333333333333333;
-  p = fma(p, e.r, 0.041666666666666664);
-  p = fma(p, e.r, 0.16666666666666666);
+  // The first two steps are spelled as three-address v_fma_f64: the compiler picks the two-address
+  // v_fmac_f64 and then has to copy the (register-resident) constant in front of each, 3 moves
+  // per value; 0.5 and 1.0 below are inline constants and need none.
+  double p, c4 = 0.041666666666666664, c3 = 0.16666666666666666;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(0.008333333333333333), "v"(e.r), "v"(c4));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(e.r), "v"(c3));
   p = fma(p, e.r, 0.5);
   p = fma(p, e.r, 1.0);
   p = fma(p, e.r, 1.0);
