@@ -836,6 +836,8 @@ __device__ __forceinline__ double near_poly(const double *line_tab, double ax) {
 // Template parameters: NTW B tiles per wave, TS tile split, kChunkSteps records per LDS chunk,
 // TW tiles that take the weight w (the rest take u; TS*NTW tiles in all, zero-padded), LINES
 // number of Lyman lines when known at compile time (0: read num_lines at run time).
+__device__ __forceinline__ uint32_t hi_word(double v) { return (uint32_t)__double2hiint(v); }
+
 // Wing-tier optical-depth sum for the three-line case (Ly-alpha, beta, gamma): FMA-form
 // velocities, ONE reciprocal for the three lines (1/(sa sb sc), then peeled), 6-term series.
 // Returns Sum_j lead_j y_j [Re w_j sqrt(pi)/y_j]; *near: some line within 30 Doppler widths.
@@ -845,13 +847,17 @@ __device__ __forceinline__ double wing_sum3(double lamP, double msa, double msb,
   // x^2 + y^2 in one FMA; "near" is then tested on it (a threshold shift of y^2 <= 3e-7 in x^2,
   // immaterial: both tiers are accurate on either side of |x| = 30)
   const double sa = fma(xa, xa, g_lines.y2[0]), sb = fma(xb, xb, g_lines.y2[1]), sc = fma(xc, xc, g_lines.y2[2]);
-  *near = (sa < 900.0) | (sb < 900.0) | (sc < 900.0);
+  // some s < 900: on the high words, as unsigned integers -- positive doubles order like their bit
+  // patterns and 900.0 has a zero low word, so s < 900.0 <=> hi(s) < hi(900.0); one three-way
+  // integer minimum and one compare instead of two fp64 minima and a compare.
+  static_assert(__builtin_bit_cast(unsigned long long, 900.0) == 0x408C200000000000ull, "bits of 900.0");
+  *near = min(min(hi_word(sa), hi_word(sb)), hi_word(sc)) < 0x408C2000u;
   const double pab = sa * sb, pbc = sb * sc, pac = sa * sc;
   const double rinv = fast_rcp(pab * sc);
   const double ra = rinv * pbc, rb = rinv * pac, rc = rinv * pab;
   // T(rho) - 2 y^2 rho^2 by Horner; the -2 y_j^2 correction rides in the rho^2 coefficient (t2[j]).
-  // The leading step is a multiply and an add (not an FMA onto a preloaded constant: that costs
-  // two extra moves per line on this ISA); the term it rounds is <= 6e-13 of the sum, the rounding <= 1e-28.
+  // The leading step as a three-address v_fma_f64 with kE4 in a vector register (the compiler
+  // would pick v_fmac_f64 and copy the constant in front of each: two extra moves per line).
   double ta = ra * kE5 + kE4, tb = rb * kE5 + kE4, tc = rc * kE5 + kE4;
   ta = fma(ta, ra, kE3); tb = fma(tb, rb, kE3); tc = fma(tc, rc, kE3);
   ta = fma(ta, ra, g_lines.t2[0]); tb = fma(tb, rb, g_lines.t2[1]); tc = fma(tc, rc, g_lines.t2[2]);
