@@ -961,7 +961,7 @@ __device__ unsigned long long g_stamps[8];
 template <typename T, int WAVES, int NTW, int TS, int kChunkSteps, int TW, int LINES>
 __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   extern __shared__ double smem[];
-  static_assert(kChunkSteps == 4 || kChunkSteps == 2 || kChunkSteps == 1, "chunks of 4, 2 or 1 K-steps");
+  static_assert(kChunkSteps == 8 || kChunkSteps == 4 || kChunkSteps == 2 || kChunkSteps == 1, "chunks of 8, 4, 2 or 1 K-steps");
   // chunks unrolled per loop iteration so that 4 K-steps (one turn of the 16-slot ring) are
   // straight-line code with compile-time ring slots and stage-buffer addresses
   constexpr int UN = kChunkSteps == 2 ? 2 : 1;
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         const double *rec = buf + (size_t)tt * RD;
         const double *extra = rec + NT * TD;
         // ring slot of pixel 4 rn (+ jj, folded into my_ring); compile-time when chunks are 4 long
-        const int slot_p = kChunkSteps == 4 ? 4 * tt : (kChunkSteps == 2 ? 4 * (2 * hc + tt) : ((4 * rn) & 15));
+        const int slot_p = kChunkSteps >= 4 ? (4 * tt) & 15 : (kChunkSteps == 2 ? 4 * (2 * hc + tt) : ((4 * rn) & 15));
         const int slot_w = (slot_p + 12) & 15;
         // lam_next was requested before the previous MFMA burst and has long landed: saying so
         // (s_waitcnt lgkmcnt(0), free) lets the raw chain start under the 15 reads issued next

@@ -5,7 +5,7 @@ set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 SRC=$ROOT/gp_dla_detection_amd/csrc/gpdla.hip
 FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -Wno-inline-asm"
-KERNEL=${1:-_ZN5gpdla7k_sweepIdLi8ELi14ELi1ELi4ELi13ELi3EEEvNS_9SweepArgsE}
+KERNEL=${1:-_ZN5gpdla7k_sweepIdLi8ELi14ELi1ELi8ELi13ELi3EEEvNS_9SweepArgsE}
 mkdir -p /tmp/gpdla_asm
 hipcc $FLAGS -Rpass-analysis=kernel-resource-usage $SRC -o /tmp/gpdla_asm/lib_remarks.so 2>&1 \
   | grep -E "error|$KERNEL" -A9 | grep -E "error|Name|VGPRs:|Spill|ScratchSize" || true
