@@ -467,7 +467,7 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   chk(dev_alloc(&b->d_pix, (size_t)rows));
   chk(dev_alloc(&b->d_Mi, (size_t)rows * b->k));
   chk(dev_alloc(&b->d_lam, (size_t)lam));
-  chk(dev_alloc(&b->d_records, (size_t)(rows / 4) * record_doubles(b->ntiles, 0)));
+  chk(dev_alloc(&b->d_records, (size_t)(rows / 4 + kRecordPoolPad) * record_doubles(b->ntiles, 0)));
   if (!md) {
     chk(dev_alloc(&b->d_sample_ll, (size_t)nq * b->S));
     chk(dev_alloc(&b->d_ll_no, (size_t)nq));

@@ -335,7 +335,8 @@ constexpr int kCompactTiles = 14, kXW = 2, kXU = 4, kXWColumn = 208, kXUColumn =
 __host__ __device__ constexpr bool tiles_compact(int ntiles) { return ntiles == kCompactTiles; }
 // doubles of per-step extras behind the tiles of a record
 // (compact: 4 x 11 used of 64, which also makes a record a whole number of 512-byte tiles)
-__host__ __device__ constexpr int record_extras(int ntiles) { return tiles_compact(ntiles) ? 64 : 32; }
+// (other classes: 20 used of 128, which makes a record a whole number of KiB for the chunk copy)
+__host__ __device__ constexpr int record_extras(int ntiles) { return tiles_compact(ntiles) ? 64 : 128; }
 // offsets into the extras of pixel jj's PixelRow and of its padded wavelength; compact class: of
 // its m columns 16..19 and vech columns 208, 209 relative to the PixelRow
 __host__ __device__ constexpr int extras_row(int ntiles, int jj) { return tiles_compact(ntiles) ? 16 * jj : 4 * jj; }
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
       double v = 0.0;
       // (pixel, field): field 0..3 PixelRow, 4 wavelength, 5..8 m columns 16.., 9, 10 vech 208, 209
       int jj = -1, f = 0;
-      if (xtra > 32) {  // compact class: per-pixel blocks
+      if (tiles_compact(a.ntiles)) {  // compact class: per-pixel blocks
         const int o = r2 & 15;
         jj = r2 >> 4;
         f = o < 4 ? o : o < 4 + kXU ? 5 + (o - 4) : o < 4 + kXU + kXW ? 9 + (o - 4 - kXU) : o == 10 ? 4 : -1;
@@ -558,6 +559,57 @@ __device__ __forceinline__ void glds16(const double *gsrc, double *lds_wave_base
 __device__ __forceinline__ void glds_wait() {
   __builtin_amdgcn_s_waitcnt(0x0F70);
   asm volatile("" ::: "memory");
+}
+
+// A whole chunk, KIB KiB-blocks long, copied global -> LDS by the WAVES waves of a block.  One
+// global_load_lds_dwordx4 moves 1 KiB (lane l: 16 bytes at +16 l on both sides), and the
+// instruction's immediate offset moves BOTH addresses (tools/glds_offset_probe.hip), so four
+// instructions share one M0 and one address register; each wave takes a contiguous span of PER
+// blocks.  Per chunk and wave that is two or three vector instructions where a loop over
+// (unit < units ? glds16 : skip) costs eight per block -- and non-arithmetic VALU instructions are
+// MFMA time in these kernels.  The copy always moves the whole chunk: a chunk that runs past a
+// quasar's last record reads the next quasar's records or the pool's padding (gpdla.hip allocates
+// kRecordPoolPad records behind the pool), which no K-step consumes.
+constexpr int kRecordPoolPad = 8;
+__device__ __forceinline__ void glds_quad(const double *gsrc, uint32_t lds, int count) {
+  if (count >= 4)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:1024\n\tglobal_load_lds_dwordx4 %0, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:3072"
+                 :
+                 : "v"(gsrc), "s"(lds)
+                 : "memory", "m0");
+  else if (count == 3)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:1024\n\tglobal_load_lds_dwordx4 %0, off offset:2048"
+                 :
+                 : "v"(gsrc), "s"(lds)
+                 : "memory", "m0");
+  else if (count == 2)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\t"
+                 "global_load_lds_dwordx4 %0, off offset:1024"
+                 :
+                 : "v"(gsrc), "s"(lds)
+                 : "memory", "m0");
+  else if (count == 1)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds) : "memory", "m0");
+}
+// src: the chunk's first double in global memory; lds: byte address of its LDS buffer; wave: this
+// wave's index within the block -- all three wave-uniform (scalar registers).
+template <int KIB, int WAVES>
+__device__ __forceinline__ void glds_chunk(const double *src, uint32_t lds, int wave, int lane) {
+  constexpr int PER = (KIB + WAVES - 1) / WAVES;
+  const int first = wave * PER;
+  const int count = min(PER, KIB - first);  // <= 0 for waves behind the last block
+  const double *p = src + (size_t)first * 128 + 2 * lane;
+  const uint32_t l = lds + (uint32_t)first * 1024u;
+#pragma unroll
+  for (int g = 0; g < (PER + 3) / 4; ++g)
+    if (count > 4 * g) glds_quad(p + g * 512, l + (uint32_t)g * 4096u, count - 4 * g);
+}
+// LDS byte address of a pointer into the dynamic shared array
+__device__ __forceinline__ uint32_t lds_address(const void *p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
 
 // Epilogue shared by the sweep kernels: one round (MFMA result register r) of the per-sample
@@ -1024,16 +1076,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
   const int nchunks = (m.steps + kChunkSteps - 1) / kChunkSteps;
 
-  // asynchronous global -> LDS copy of one chunk of records (1 KiB per wave-instruction)
+  // asynchronous global -> LDS copy of one chunk of records (see glds_chunk)
+  static_assert((kChunkSteps * RD) % 128 == 0, "a chunk is a whole number of KiB");
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t stage_lds = __builtin_amdgcn_readfirstlane(lds_address(stage));
   auto issue_chunk = [&](int c) {
-    const int csteps = min(kChunkSteps, m.steps - c * kChunkSteps);
-    const int units = csteps * (RD / 2);  // 16-byte units
-    const double *src = rec_base + (size_t)c * kChunkSteps * RD;
-    double *dst = stage + (size_t)(c & 1) * kChunkSteps * RD;
-    for (int i = wave; i * 64 < units; i += WAVES) {
-      const int unit = i * 64 + lane;
-      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)i * 128);
-    }
+    glds_chunk<kChunkSteps * RD / 128, WAVES>(rec_base + (size_t)c * kChunkSteps * RD,
+                                              stage_lds + (uint32_t)(c & 1) * (uint32_t)(kChunkSteps * RD * 8), wave_s, lane);
   };
   issue_chunk(0);
 
