@@ -215,15 +215,12 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
   const int nrec = m.steps + 1;
   const int nchunks = (nrec + kChunkSteps - 1) / kChunkSteps;
-  auto issue_chunk = [&](int c) {
-    const int csteps = min(kChunkSteps, nrec - c * kChunkSteps);
-    const int units = csteps * (RD / 2);
-    const double *src = rec_base + (size_t)c * kChunkSteps * RD;
-    double *dst = stage + (size_t)(c & 1) * kChunkSteps * RD;
-    for (int u = wave; u * 64 < units; u += kSweepWaves) {
-      const int unit = u * 64 + lane;
-      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)u * 128);
-    }
+  static_assert((kChunkSteps * RD) % 128 == 0, "a chunk is a whole number of KiB");
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t stage_lds = __builtin_amdgcn_readfirstlane(lds_address(stage));
+  auto issue_chunk = [&](int c) {  // (see glds_chunk in sweep_kernels.hpp)
+    glds_chunk<kChunkSteps * RD / 128, kSweepWaves>(rec_base + (size_t)c * kChunkSteps * RD,
+                                                    stage_lds + (uint32_t)(c & 1) * (uint32_t)(kChunkSteps * RD * 8), wave_s, lane);
   };
   issue_chunk(0);
   d4 acc[NTW];

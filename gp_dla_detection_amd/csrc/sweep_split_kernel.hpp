@@ -90,15 +90,12 @@ __global__ __launch_bounds__(512) void k_sweep_split(SweepArgs a) {
   const double cs = c_light * inv_s;
   const double tap0 = g_lines.taps[0], tap1 = g_lines.taps[1], tap2 = g_lines.taps[2], tap3 = g_lines.taps[3];
 
-  auto issue_chunk = [&](int c) {
-    const int csteps = min(CH, m.steps - c * CH);
-    const int units = csteps * (RD / 2);  // 16-byte units
-    const double *src = rec_base + (size_t)c * CH * RD;
-    double *dst = stage + (size_t)(c & 1) * CH * RD;
-    for (int i = wave; i * 64 < units; i += WAVES) {
-      const int unit = i * 64 + lane;
-      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)i * 128);
-    }
+  static_assert((CH * RD) % 128 == 0, "a chunk is a whole number of KiB");
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t stage_lds = __builtin_amdgcn_readfirstlane(lds_address(stage));
+  auto issue_chunk = [&](int c) {  // (see glds_chunk in sweep_kernels.hpp)
+    glds_chunk<CH * RD / 128, WAVES>(rec_base + (size_t)c * CH * RD, stage_lds + (uint32_t)(c & 1) * (uint32_t)(CH * RD * 8),
+                                     wave_s, lane);
   };
   issue_chunk(0);
 
