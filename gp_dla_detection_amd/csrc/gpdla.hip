@@ -973,7 +973,7 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
         sa.sample_ll_dla = mb.sll_dla;
         sa.sample_ll_lls = mb.sll_lls;
         sa.ll_no_dla = mb.ll_no;
-        rc = b->k <= 20 ? launch_sweep_multi<14, 1, 4, 13>(c, b, sa) : launch_sweep_multi<14, 4, 1, 52>(c, b, sa);
+        rc = b->k <= 20 ? launch_sweep_multi<14, 1, 8, 13>(c, b, sa) : launch_sweep_multi<14, 4, 1, 52>(c, b, sa);
         if (rc) return rc;
       }
       // evidence, MAP, early-exit flags for the quasars of this sub-batch

@@ -15,6 +15,8 @@
 //                                      reference uses MATLAB's rng('default') + randsample)
 //   k_multi_posteriors multi :482-495
 #pragma once
+#include <type_traits>
+
 #include "sweep_kernels.hpp"
 
 namespace gpdla {
@@ -231,15 +233,33 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
   int dexp = 0;
   const int tile0 = role * NTW;
 
-  // absorption of pixel p for this lane's sample: product of the gathered profiles
-  auto absorption = [&](int p) -> double {
-    double v = rows[0][p];
-    if (ND > 1) v *= rows[1][p];
-    if (ND > 2) v *= rows[2][p];
-    if (ND > 3) v *= rows[3][p];
+  // absorption of pixel p for this lane's sample: product of the gathered profiles.  The gather
+  // reads HBM (the profile table is 243 MB per quasar) and a K-step of this kernel is short -- 14
+  // MFMAs and ~35 vector instructions, ~1 us per wave -- so the values are requested kAhead K-steps
+  // before they are used: with a single step of lookahead every K-step waited for its own gather
+  // (PMC, round 2: the matrix pipe busy 65 % of the time with 16 % of it idle on both waves).
+  constexpr int kAhead = 3;
+  double raw0_product;
+  auto gather = [&](int p, double (&r)[ND]) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) r[j] = rows[j][p];
+  };
+  auto product = [&](const double (&r)[ND]) -> double {
+    double v = r[0];
+#pragma unroll
+    for (int j = 1; j < ND; ++j) v *= r[j];
     return is_null ? 1.0 : v;
   };
-  double a_next = absorption(jj);  // step 0
+  const int p_last = 4 * m.steps + jj;  // rows are padded to 4*(steps+1) entries
+  double raw[kAhead][ND];               // raw[i]: gathered for K-step (t + 1 + i) mod kAhead at use
+  {
+    double r0[ND];
+    gather(jj, r0);
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) gather(min(4 * (1 + i) + jj, p_last), raw[i]);
+    raw0_product = product(r0);
+  }
+  double a_next = raw0_product;  // step 0
   glds_wait();
   __syncthreads();
   if (nchunks > 1) issue_chunk(1);
@@ -270,7 +290,10 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     _Pragma("unroll") for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt_[(size_t)cc * 64];    \
   }
   GPDLA_MPREP(stage, a_next)
-  for (int t = 0; t < m.steps; ++t) {
+  // one K-step; I = t mod kAhead selects the gather slot at compile time (the loop is unrolled
+  // kAhead times so that the slots rotate without register moves)
+  auto kstep = [&](auto I, int t) {
+    constexpr int i = decltype(I)::value;
     const int rn = t + 1;
     const int cn = rn / kChunkSteps;
     if (rn % kChunkSteps == 0) {
@@ -279,7 +302,8 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
       if (cn + 1 < nchunks) issue_chunk(cn + 1);
     }
     const double *rec = stage + ((size_t)(cn & 1) * kChunkSteps + (rn % kChunkSteps)) * RD;
-    a_next = absorption(4 * rn + jj);  // rows are padded to 4*(steps+1) entries
+    a_next = product(raw[i]);                                    // K-step rn, requested kAhead steps ago
+    gather(min(4 * (rn + kAhead) + jj, p_last), raw[i]);         // K-step rn + kAhead
     const double wa = w_cur, ua = u_cur;
 #pragma unroll
     for (int cc = 0; cc < NTW; ++cc)
@@ -296,6 +320,12 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
       for (int x = 0; x < kXU; ++x) xu[x] = fma(ua, upr[x], xu[x]);
     }
     GPDLA_MPREP(rec, a_next)
+  };
+  static_assert(kAhead == 3, "the loop below is unrolled three times");
+  for (int t = 0; t < m.steps; t += kAhead) {
+    kstep(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < m.steps) kstep(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < m.steps) kstep(std::integral_constant<int, 2>{}, t + 2);
   }
 #undef GPDLA_MPREP
   __syncthreads();
