@@ -1346,9 +1346,9 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
     if ((rc = dev_alloc(&t->d_wA, tiled)) || (rc = dev_alloc(&t->d_uA, tiled)) ||
         (rc = dev_alloc(&t->d_wB, (size_t)d.PG * d.TQ * 64)) || (rc = dev_alloc(&t->d_uB, (size_t)d.PG * d.TQ * 64)) ||
         (rc = dev_alloc(&t->d_part1, (size_t)d.NQ16 * 16 * d.PB * 3)) ||
-        (rc = dev_alloc(&t->d_recM, (size_t)d.T * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recP, (size_t)d.PG * kTrKs * 64)) ||
+        (rc = dev_alloc(&t->d_recM, (size_t)(d.T + kTrChunk) * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recP, (size_t)d.PG * kTrKs * 64)) ||
         (rc = dev_alloc(&t->d_partB, (size_t)d.NQ16 * d.H * 16 * kTrCols)) ||
-        (rc = dev_alloc(&t->d_recD, (size_t)d.TQ * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recE, (size_t)d.NQ16 * kTrKs * 64)) ||
+        (rc = dev_alloc(&t->d_recD, (size_t)(d.TQ + kTrChunk) * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recE, (size_t)d.NQ16 * kTrKs * 64)) ||
         (rc = dev_alloc(&t->d_nlogp, (size_t)d.NQ16 * 16)) ||
         (rc = dev_alloc(&t->d_partD, (size_t)d.PG * d.H2 * 16 * kTrCols)) ||
         (rc = dev_alloc(&t->d_partcol, (size_t)d.PG * d.GS * 16)) || (rc = dev_alloc(&t->d_partsc, (size_t)d.PG * d.GS * 3)) ||

@@ -221,16 +221,14 @@ __global__ __launch_bounds__(kTrCWaves * 64) void k_train_contract(TrainContract
 #pragma unroll
   for (int c = 0; c < kTrTiles; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
   const double *aw = a.Aw + ((active ? r : 0) * a.steps) * 64 + lane, *au = a.Au + ((active ? r : 0) * a.steps) * 64 + lane;
+  // whole chunks, copied as per-wave spans (glds_chunk, sweep_kernels.hpp); a chunk that runs past
+  // t1 reads the following steps' records or the kTrChunk records of padding behind the array
+  static_assert((kTrChunk * kTrRecD) % 128 == 0, "a chunk is a whole number of KiB");
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t smem_lds = __builtin_amdgcn_readfirstlane(lds_address(smem));
   auto issue_chunk = [&](int c) {
-    const int64_t ts = t0 + (int64_t)c * kTrChunk;
-    const int csteps = (int)min((int64_t)kTrChunk, t1 - ts);
-    const int units = csteps * (kTrRecD / 2);  // 16-byte units
-    const double *src = a.Brec + ts * kTrRecD;
-    double *dst = smem + (size_t)(c & 1) * kTrChunk * kTrRecD;
-    for (int i = wave; i * 64 < units; i += kTrCWaves) {
-      const int unit = i * 64 + lane;
-      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)i * 128);
-    }
+    glds_chunk<kTrChunk * kTrRecD / 128, kTrCWaves>(a.Brec + (t0 + (int64_t)c * kTrChunk) * kTrRecD,
+                                                    smem_lds + (uint32_t)(c & 1) * (uint32_t)(kTrChunk * kTrRecD * 8), wave_s, lane);
   };
   double wn[kTrChunk], un[kTrChunk];
   auto load_a = [&](int c) {
@@ -521,14 +519,12 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
 #pragma unroll
   for (int ks = 0; ks < kTrKs; ++ks) bP[ks] = active ? a.recP[(pt * kTrKs + ks) * 64 + lane] : 0.0;
   const double om = (active && p < D.G) ? a.omega2[p] : 0.0;
-  auto issue_group = [&](int64_t g) {
-    const int units = kTrKs * 32;  // 16-byte units
-    const double *src = a.recE + g * kTrKs * 64;
-    double *dst = smem + (size_t)((g - g0) & 1) * kTrKs * 64;
-    for (int i = wave; i * 64 < units; i += 4) {
-      const int unit = i * 64 + lane;
-      if (unit < units) glds16(src + 2 * (size_t)unit, dst + (size_t)i * 128);
-    }
+  static_assert((kTrKs * 64) % 128 == 0, "a quasar group's operands are a whole number of KiB");
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t smem_lds = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  auto issue_group = [&](int64_t g) {  // (glds_chunk, sweep_kernels.hpp)
+    glds_chunk<kTrKs * 64 / 128, 4>(a.recE + g * kTrKs * 64, smem_lds + (uint32_t)((g - g0) & 1) * (uint32_t)(kTrKs * 64 * 8),
+                                    wave_s, lane);
   };
   if (g0 < g1) issue_group(g0);
   double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
