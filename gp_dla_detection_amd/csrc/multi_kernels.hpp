@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
     ms[j] = mult[j] * inv_s;
   }
   const double cs = c_light * inv_s;
-  const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
+  const double nscale64 = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;  // (pre-scaled exp, sweep_kernels.hpp)
   const double *lam = a.lam_pad + m.lam_off;
   const int n_pad = m.n_u + 6;
   double *rows = a.prof + ((ql * 2 + kind) * a.S) * a.stride;  // + i * stride + p
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
                            : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
       }
     }
-    return exp_table(nscale * total, s_exp);  // voigt.c:291
+    return exp_table_scaled(nscale64 * total, s_exp);  // voigt.c:291
   };
 
   // window of raw values P .. P+6 for output pixel P (the profile of pixel p uses padded p .. p+6)

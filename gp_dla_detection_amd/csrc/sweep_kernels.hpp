@@ -983,6 +983,9 @@ __device__ __forceinline__ double exp_table_end_scaled(const ExpState &e) {
 __device__ __forceinline__ double exp_table(double x, const double *tab) {
   return exp_table_end(exp_table_begin(x, tab));
 }
+__device__ __forceinline__ double exp_table_scaled(double t, const double *tab) {  // t = x * kExpScale
+  return exp_table_end_scaled(exp_table_begin_scaled(t, tab));
+}
 
 // Optical-depth sum sqrt(pi) Sum_j lead_j Re w_j where some line is within 30 Doppler widths
 // (voigt.c:282-289, reference two-rounding velocity): per line either the piecewise polynomial or
@@ -1099,8 +1102,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   const double *lam = a.lam_pad + m.lam_off;
   const int n_pad = m.n_u + 6;
   // exp(N * total / (sqrt(2 pi) sigma)) with total = -Sum lead_j Re w_j (voigt.c:288-291)
-  const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
-  const double nscale64 = nscale * kExpScale;  // for the K-loop's pre-scaled exp
+  // (times 64/ln2: the exp below takes its argument pre-scaled, exp_table_begin_scaled)
+  const double nscale64 = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;
   const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
   const int nchunks = (m.steps + kChunkSteps - 1) / kChunkSteps;
 
@@ -1125,7 +1128,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #define GPDLA_TOTAL_ACCURATE(lamP)                                                        \
   total_near<LINES>((lamP), mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], \
                     my_mult, L)
-#define GPDLA_RAW_ACCURATE(lamP) exp_table(nscale * GPDLA_TOTAL_ACCURATE(lamP), exp_tab)
+#define GPDLA_RAW_ACCURATE(lamP) exp_table_scaled(nscale64 * GPDLA_TOTAL_ACCURATE(lamP), exp_tab)
 
   __syncthreads();  // multipliers and the exp table visible
   // prime the ring with padded pixels 0..11 (the raw profile runs three K-steps ahead)
@@ -1134,8 +1137,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
     double v;
     if (LINES == 3) {
       bool near0;
-      v = exp_table(nscale * wing_sum3(lam0, ms_r[0], ms_r[LINES > 1 ? 1 : 0], ms_r[LINES > 2 ? 2 : 0],
-                                       cs, &near0), exp_tab);
+      v = exp_table_scaled(nscale64 * wing_sum3(lam0, ms_r[0], ms_r[LINES > 1 ? 1 : 0], ms_r[LINES > 2 ? 2 : 0],
+                                                cs, &near0), exp_tab);
       if (__any(near0)) v = GPDLA_RAW_ACCURATE(lam0);
     } else {
       v = GPDLA_RAW_ACCURATE(lam0);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void k_sweep_split(SweepArgs a) {
   const double *lam = a.lam_pad + m.lam_off;
   const PixelRow *pix = a.pix + m.pix_off;
   const int n_pad = m.n_u + 6;
-  const double nscale = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi;
+  const double nscale64 = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;  // (pre-scaled exp, sweep_kernels.hpp)
   const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
   const int nchunks = (m.steps + CH - 1) / CH;
   const int niter = (m.steps + 3) / 4;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512) void k_sweep_split(SweepArgs a) {
     }
     if (__builtin_expect(__any(near), 0))
       total = total_near<LINES>(lamP, mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], my_mult, L);
-    return exp_table(nscale * total, exp_tab);
+    return exp_table_scaled(nscale64 * total, exp_tab);
   };
   auto lam_of = [&](int tr) -> double { return lam[min(4 * tr + jj, n_pad - 1)]; };
   auto pix_of = [&](int t) -> PixelRow { return pix[4 * min(t, m.steps) + jj]; };  // row `steps` is neutral
