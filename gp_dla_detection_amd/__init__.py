@@ -5,10 +5,10 @@ for gfx950: hand-written HIP kernels behind a C-ABI (``include/gpdla.h``), with 
 Python host side mirroring the reference's call surface.  See DESIGN.md.
 """
 from .api import (Batch, Context, dla_existence_prior, dla_existence_prior_multi,
-                  log_mvnpdf_low_rank, process_qsos, process_qsos_multiple_dlas_meanflux,
-                  spectra_to_csr, voigt)
+                  log_mvnpdf_low_rank, prepare_prior, process_qsos,
+                  process_qsos_multiple_dlas_meanflux, spectra_to_csr, voigt)
 from .parameters import MultiParameters, Parameters, kms_to_z
 
 __all__ = ["Batch", "Context", "dla_existence_prior", "dla_existence_prior_multi",
-           "log_mvnpdf_low_rank", "process_qsos", "process_qsos_multiple_dlas_meanflux",
+           "log_mvnpdf_low_rank", "prepare_prior", "process_qsos", "process_qsos_multiple_dlas_meanflux",
            "spectra_to_csr", "voigt", "Parameters", "MultiParameters", "kms_to_z"]

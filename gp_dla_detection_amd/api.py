@@ -84,6 +84,27 @@ def log_mvnpdf_low_rank(y, mu, M, d, device: int = 0) -> float:
     return out.value
 
 
+def prepare_prior(prior_z_qsos, prior_dla_ind, prior_z_dlas, params: Parameters | None = None) -> dict:
+    """process_qsos.m:11-27: the training catalogue's (z_QSO, has-a-DLA) pairs behind the model
+    prior, with a sightline's flag cleared when any of its catalogued DLAs lies blueward of the
+    quasar's Lyman limit -- ``observed_wavelengths(lya_wavelength, z_dla) <
+    observed_wavelengths(lyman_limit, z_qso)`` (:21-25) -- where this search never looks.
+    ``prior_z_dlas[i]`` is the list of DLA redshifts of sightline i (the cell of
+    ``prior_catalog.z_dlas(dla_catalog_name)``); it is read only where ``prior_dla_ind[i]``.
+    Returns ``dict(z_qsos, dla_ind)`` as :func:`process_qsos` takes for ``prior_catalog``."""
+    p = params or Parameters()
+    z = np.asarray(prior_z_qsos, dtype=np.float64).reshape(-1)
+    ind = np.array(prior_dla_ind, dtype=bool).reshape(-1)
+    if ind.size != z.size or len(prior_z_dlas) != z.size:
+        raise ValueError("prior_z_qsos, prior_dla_ind and prior_z_dlas must have one entry per sightline")
+    for i in np.flatnonzero(ind):
+        z_dlas = np.atleast_1d(np.asarray(prior_z_dlas[i], dtype=np.float64))
+        # MATLAB's `if (vector < scalar)` is true only when every element is
+        if z_dlas.size and np.all(p.lya_wavelength * (1 + z_dlas) < p.lyman_limit * (1 + z[i])):
+            ind[i] = False
+    return dict(z_qsos=z, dla_ind=ind)
+
+
 def dla_existence_prior(prior_z_qsos, prior_dla_ind, z_qsos, params: Parameters | None = None):
     """process_qsos.m:122-131: log p(DLA | z_QSO) and log p(no DLA | z_QSO) from the counts of
     training-catalog quasars with z < z_QSO + prior_z_qso_increase.  Host logic (SURVEY.md

@@ -187,3 +187,21 @@ def test_prior_matches_counting_definition():
         n, m = np.count_nonzero(less), np.count_nonzero(pd[less])
         assert log_dla[i] == np.log(m) - np.log(n)
         assert log_no[i] == np.log(n - m) - np.log(n)
+
+
+def test_prepare_prior_clears_flags_for_dlas_below_the_lyman_limit():
+    """process_qsos.m:11-27: a sightline stops counting as "has a DLA" when ALL its catalogued DLAs
+    lie blueward of the quasar's Lyman limit (MATLAB's `if vector` is true only if every element is)."""
+    import gp_dla_detection_amd as gp
+    p = gp.Parameters()
+    z_qsos = np.array([3.0, 3.0, 3.0, 2.5, 3.2])
+    z_limit = p.lyman_limit * (1 + 3.0) / p.lya_wavelength - 1  # Lya of a DLA at the z = 3 quasar's limit
+    z_dlas = [[z_limit - 0.01], [z_limit + 0.01], [z_limit - 0.2, z_limit + 0.3], [], [1.0]]
+    dla_ind = np.array([True, True, True, False, False])
+    out = gp.prepare_prior(z_qsos, dla_ind, z_dlas)
+    assert out["dla_ind"].tolist() == [False, True, True, False, False]
+    assert dla_ind.tolist() == [True, True, True, False, False]  # the input is not modified
+    lp_no, lp_dla = gp.dla_existence_prior(out["z_qsos"], out["dla_ind"], np.array([3.5]))
+    assert np.isclose(np.exp(lp_dla[0]), 2 / 5) and np.isclose(np.exp(lp_no[0]), 3 / 5)
+    with pytest.raises(ValueError):
+        gp.prepare_prior(z_qsos, dla_ind[:3], z_dlas)
