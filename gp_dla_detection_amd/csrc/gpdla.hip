@@ -133,6 +133,15 @@ void dev_free(void *p) {
   if (p) (void)hipFree(p);
 }
 
+// Drains a stream when it leaves scope.  Declared AFTER the host buffers that asynchronous copies on
+// that stream write into, so that on every exit path -- the error returns included -- the copies have
+// finished before those buffers are destroyed (a copy engine still writing into a freed std::vector
+// would corrupt the heap).
+struct StreamDrain {
+  hipStream_t stream;
+  ~StreamDrain() { (void)hipStreamSynchronize(stream); }
+};
+
 }  // namespace
 
 struct gpdla_context {
@@ -695,6 +704,7 @@ int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) {
   const size_t nq = (size_t)b->nq;
   std::vector<double> summary(nq * GPDLA_SUMMARY_COLS);
   std::vector<QuasarMeta> meta(nq);
+  StreamDrain drain{c->stream};
   HIP_TRY(hipMemcpyAsync(summary.data(), b->d_summary, summary.size() * sizeof(double),
                          hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(meta.data(), b->d_meta, nq * sizeof(QuasarMeta), hipMemcpyDeviceToHost, c->stream));
@@ -928,9 +938,12 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
   HIP_TRY(hipMemsetAsync(mb.map_n, 0xFF, nqs * md * md * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(mb.map_i, 0xFF, nqs * md * md * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(mb.alive, 0x01, nqs * sizeof(int32_t), st));
-  if (base_in && nbase)
+  if (base_in && nbase) {
+    // the caller's buffer is consumed before this call returns (gpdla.h): a pageable source may
+    // otherwise still be read by the copy engine after the caller has freed it
     HIP_TRY(hipMemcpyAsync(mb.base, base_in, nbase * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  else
+    HIP_TRY(hipStreamSynchronize(st));
+  } else
     HIP_TRY(hipMemsetAsync(mb.base, 0, (nbase ? nbase : 1) * sizeof(uint32_t), st));
 
   const int64_t nq_sub = mb.prof_quasars, stride = mb.prof_stride;
@@ -1062,6 +1075,7 @@ int gpdla_batch_download_multi(gpdla_context *c, gpdla_batch *b, gpdla_results_m
   int rc = GPDLA_OK;
   auto chk = [&](int x) { if (x && !rc) rc = x; };
   std::vector<QuasarMeta> meta(nqs);
+  StreamDrain drain{st};  // (also covers the caller's arrays: nothing is in flight once this returns)
   HIP_TRY(hipMemcpyAsync(meta.data(), b->d_meta, nqs * sizeof(QuasarMeta), hipMemcpyDeviceToHost, st));
   auto dl = [&](void *dst, const void *src, size_t bytes) -> int {
     if (dst && bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
