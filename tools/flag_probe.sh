@@ -9,7 +9,7 @@ SRC=gp_dla_detection_amd/csrc/gpdla.hip
 FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -Wno-inline-asm"
 mkdir -p /tmp/ablate gpurun_out
 for v in "$@"; do
-  hipcc $FLAGS $v $SRC -o /tmp/ablate/lib_flag.so
+  if ! hipcc $FLAGS $v $SRC -o /tmp/ablate/lib_flag.so 2>/tmp/ablate/flag_err.txt; then echo "flags '$v' did not compile: $(tail -1 /tmp/ablate/flag_err.txt)" | tee -a gpurun_out/flag_probe.txt; continue; fi
   if [ "${GPDLA_PROBE_TARGET:-sweep}" = training ]; then
     ms=$(GPDLA_LIB_PATH=/tmp/ablate/lib_flag.so python3 tools/bench_training.py 2>/dev/null | python3 -c "import sys,json; print(1e3*json.loads(sys.stdin.readline())['gpu_seconds_per_eval'])")
   else
