@@ -646,7 +646,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   const bool f32 = c->cfg.contraction_precision == 1;
   if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
     if (!f32) rc = three ? launch_sweep<double, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
-    else rc = three ? launch_sweep<float, 8, 14, 1, 4, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
+    else rc = three ? launch_sweep<float, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
   } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles
     if (!f32) {  // fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
       // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k_sweep form in which every wave of a group repeats
