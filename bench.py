@@ -2,7 +2,10 @@
 """bench.py -- throughput of the GP/DLA inference sweep on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 works both ways: typed as above, this process starts the N ranks itself (child processes,
+  one per GPU, spawned BEFORE anything here touches the GPU; rendezvous on 127.0.0.1) and exits
+  with their status; under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+  bench.py --gpus N ...` (WORLD_SIZE already set) it is one of the ranks.
 
 A "step" is one pass of the hot path (gpdla_batch_process: selection + interpolation, null
 evidence, S-sample Voigt/low-rank sweep, evidence + posteriors + MAP) over one HBM-resident batch
@@ -162,6 +165,60 @@ def cpu_baseline(model, samples, spectra, seconds_target=6.0, repeats=3):
                        f"single_core_value from {one_count} samples on 1 thread (best of 3)")
 
 
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` typed directly (no WORLD_SIZE in the environment): run the N
+    ranks as child processes of this one, which has made no GPU call and makes none -- a process
+    that has initialised the GPU must neither fork nor exec on this pool.  Each child gets the
+    environment torch.distributed.run would give it (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR =
+    127.0.0.1, a free MASTER_PORT); rank 0's child prints the JSON line on the inherited stdout.
+    If a rank dies the others are ended (by their exact PIDs) instead of waiting in a collective.
+    Returns the worst exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    worst = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in alive:  # the others would wait for this rank forever
+                    q.terminate()
+    return worst
+
+
+def launch_check():
+    """--launch-check: what a rank does to prove the launch worked, with no GPU involved: rendezvous
+    over gloo, all-reduce the ranks, rank 0 prints one JSON line (tests/test_bench_launch.py)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t)
+    local = torch.tensor([float(os.environ["LOCAL_RANK"])], dtype=torch.float64)
+    dist.all_reduce(local)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": t.item(),
+                          "local_rank_sum": local.item()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,7 +236,15 @@ def main():
     ap.add_argument("--pcie", action="store_true",
                     help="also time the one-shot host-buffer entry point (H2D + sweep + D2H); "
                          "reported as config.pcie_inclusive_evals_per_s, never as value")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))  # nothing above touched the GPU
+    if args.launch_check:
+        return launch_check()
 
     import torch
     import torch.distributed as dist
@@ -192,12 +257,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world} in the environment")
     # GPDLA_BENCH_REHEARSAL=1: rehearse the multi-process path on a box with ONE GPU (every rank on
     # cuda:0, gloo instead of RCCL, the gather staged through host memory).  Never used by the driver.
     rehearsal = os.environ.get("GPDLA_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:  # device_count() does not initialise the GPU
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         if rehearsal:
@@ -208,11 +275,8 @@ def main():
     model = synthetic.make_model(args.k)
     samples = synthetic.make_samples(args.samples)
     if args.workload == "configs1":
-        # distinct spectra per rank; only a few distinct realisations are generated and tiled (the
-        # sweep's cost does not depend on the flux values)
-        distinct = min(args.spectra, 16)
-        base = synthetic.make_spectra(distinct, args.pixels, model, first_index=1000 * rank)
-        spectra = [base[i % distinct] for i in range(args.spectra)]
+        # every spectrum distinct, on every rank (as in dr12q-mix: one method for both workloads)
+        spectra = synthetic.make_spectra(args.spectra, args.pixels, model, first_index=args.spectra * rank)
         n_kept = np.full(args.spectra, args.pixels)
     else:
         spectra = synthetic.make_dr12q_mix(args.spectra, model, first_index=args.spectra * rank)
