@@ -86,7 +86,7 @@ def log_mvnpdf_low_rank(y, mu, M, d, device: int = 0) -> float:
 
 def prepare_prior(prior_z_qsos, prior_dla_ind, prior_z_dlas, params: Parameters | None = None) -> dict:
     """process_qsos.m:11-27: the training catalogue's (z_QSO, has-a-DLA) pairs behind the model
-    prior, with a sightline's flag cleared when any of its catalogued DLAs lies blueward of the
+    prior, with a sightline's flag cleared when every one of its catalogued DLAs lies blueward of the
     quasar's Lyman limit -- ``observed_wavelengths(lya_wavelength, z_dla) <
     observed_wavelengths(lyman_limit, z_qso)`` (:21-25) -- where this search never looks.
     ``prior_z_dlas[i]`` is the list of DLA redshifts of sightline i (the cell of

@@ -78,23 +78,61 @@ def _py(x):
     return x.item() if hasattr(x, "item") else x
 
 
-def generate_json_catalogue(results: dict, quasar_info: dict, outfile: str | None = None,
-                            sub_dla: bool = True) -> list:
-    """``QSOLoader.generate_json_catalogue`` (qso_loader.py:1927-2031): one record per searched
-    quasar in the form of Parks et al. (2018) -- ``p_dla, p_no_dla, max_model_posterior, num_dlas,
-    dlas: [{log_nhi, z_dla}], min_z_dla, max_z_dla, ra, snr, dec, plate, mjd, fiber_id, thing_id,
-    z_qso`` -- from the multi-DLA results (``model_posteriors`` [nq, 2+max_dlas] = (no DLA, sub-DLA,
-    1..max_dlas DLAs), ``MAP_z_dlas`` / ``MAP_log_nhis`` [nq, model, slot]).  ``quasar_info``:
-    ``ras, decs, plates, mjds, fiber_ids, thing_ids, z_qsos, snrs`` of the searched quasars (the
-    catalogue columns after the ``test_ind`` subset, qso_loader.py:114-125).  With ``sub_dla`` the
-    sub-DLA posterior counts towards "no DLA" (:100-101, :1977-1985)."""
-    mp = np.asarray(results["model_posteriors"], dtype=np.float64)
+def occams_model_posteriors(model_posteriors, occams_razor: float = 10000.0) -> np.ndarray:
+    """``QSOLoader._occams_model_posteriors`` (qso_loader.py:235-257): every model but the null one
+    is penalised by ``1 / occams_razor`` and the row renormalised.  Returns a new array."""
+    mp = np.array(model_posteriors, dtype=np.float64)
+    mp[:, 1:] = mp[:, 1:] / occams_razor                              # :247
+    return mp / np.sum(mp, axis=1)[:, None]                           # :250-252
+
+
+def loader_view(results: dict, quasar_info: dict, sub_dla: bool = True, occams_razor: float = 10000.0,
+                drop_nan: bool = True):
+    """What ``QSOLoader.__init__`` holds after loading a processed file (qso_loader.py:97-170), i.e.
+    what its catalogue methods then work on: the Occam-penalised ``model_posteriors`` (:136), ``p_dlas``
+    / ``p_no_dlas`` recomputed from them (:137-138: with ``sub_dla`` the sub-DLA model counts as "no
+    DLA"), and -- ``drop_nan`` -- the quasars whose posterior row is NaN removed from every per-quasar
+    array (:147-170; these are the quasars the sweep skipped).  ``occams_razor=1`` leaves the
+    posteriors as saved.  Returns (results view, quasar_info view, kept row indices)."""
+    mp = occams_model_posteriors(results["model_posteriors"], occams_razor)
     nq = mp.shape[0]
-    p_dlas = np.asarray(results["p_dlas"], dtype=np.float64)
-    p_no = np.asarray(results["p_no_dlas"], dtype=np.float64).copy()
-    if sub_dla:
-        p_no += mp[:, 1]                                             # qso_loader.py:100-101
-    filled = np.where(np.isnan(mp), -np.inf, mp)
+    first_dla = 1 + int(bool(sub_dla))
+    view = dict(model_posteriors=mp, p_dlas=mp[:, first_dla:].sum(axis=1),       # :137
+                p_no_dlas=mp[:, :first_dla].sum(axis=1))                         # :138
+    for key in ("min_z_dlas", "max_z_dlas", "MAP_z_dlas", "MAP_log_nhis"):
+        if key in results:
+            view[key] = np.asarray(results[key])
+    for _, col in _INFO_FIELDS:
+        if len(quasar_info[col]) != nq:
+            raise ValueError(f"quasar_info[{col!r}] has {len(quasar_info[col])} entries for {nq} quasars")
+    info = {col: np.asarray(quasar_info[col]) for _, col in _INFO_FIELDS}
+    keep = np.arange(nq)
+    if drop_nan:
+        with np.errstate(invalid="ignore"):
+            top = mp[np.arange(nq), np.argmax(mp, axis=1)]                       # :143-144 (NaN wins argmax)
+        keep = np.flatnonzero(~np.isnan(top))                                    # :147
+        view = {k: v[keep] for k, v in view.items()}
+        info = {k: v[keep] for k, v in info.items()}
+    return view, info, keep
+
+
+def generate_json_catalogue(results: dict, quasar_info: dict, outfile: str | None = None,
+                            sub_dla: bool = True, occams_razor: float = 10000.0,
+                            drop_nan: bool = True) -> list:
+    """``QSOLoader.generate_json_catalogue`` (qso_loader.py:1927-2031) as the reference produces it,
+    i.e. on the loader's view of the processed file (:func:`loader_view`: Occam factor 10000 on
+    every absorber model, ``p_dla`` / ``p_no_dla`` recomputed, NaN rows dropped -- the defaults of
+    ``QSOLoader(occams_razor=10000)``).  One record per remaining quasar in the form of Parks et al.
+    (2018): ``p_dla, p_no_dla, max_model_posterior, num_dlas, dlas: [{log_nhi, z_dla}], min_z_dla,
+    max_z_dla, ra, snr, dec, plate, mjd, fiber_id, thing_id, z_qso``.  ``results``: the multi-DLA
+    variables (``model_posteriors`` [nq, 2+max_dlas] = (no DLA, sub-DLA, 1..max_dlas DLAs),
+    ``MAP_z_dlas`` / ``MAP_log_nhis`` [nq, model, slot]).  ``quasar_info``: ``ras, decs, plates,
+    mjds, fiber_ids, thing_ids, z_qsos, snrs`` of the searched quasars (the catalogue columns after
+    the ``test_ind`` subset, qso_loader.py:114-133)."""
+    view, info, _ = loader_view(results, quasar_info, sub_dla, occams_razor, drop_nan)
+    mp, p_dlas, p_no = view["model_posteriors"], view["p_dlas"], view["p_no_dlas"]
+    nq = mp.shape[0]
+    filled = np.where(np.isnan(mp), -np.inf, mp) if not drop_nan else mp
     model_index = filled.argmax(axis=1)                              # :1973
     max_mp = mp[np.arange(nq), model_index].copy()                   # :1974
     num_dlas = model_index.copy()
@@ -103,17 +141,14 @@ def generate_json_catalogue(results: dict, quasar_info: dict, outfile: str | Non
         max_mp[inds] = p_no[inds]                                    # :1980
         num_dlas = model_index - 1                                   # :1983
         num_dlas[num_dlas < 0] = 0                                   # :1984
-    map_z, map_n = np.asarray(results["MAP_z_dlas"]), np.asarray(results["MAP_log_nhis"])
-    for _, col in _INFO_FIELDS:
-        if len(quasar_info[col]) != nq:
-            raise ValueError(f"quasar_info[{col!r}] has {len(quasar_info[col])} entries for {nq} quasars")
+    map_z, map_n = view["MAP_z_dlas"], view["MAP_log_nhis"]
     out = []
     for i in range(nq):
         spec = {"p_dla": _py(p_dlas[i]), "p_no_dla": _py(p_no[i]), "max_model_posterior": _py(max_mp[i]),
-                "num_dlas": int(num_dlas[i]), "min_z_dla": _py(np.asarray(results["min_z_dlas"])[i]),
-                "max_z_dla": _py(np.asarray(results["max_z_dlas"])[i])}
+                "num_dlas": int(num_dlas[i]), "min_z_dla": _py(view["min_z_dlas"][i]),
+                "max_z_dla": _py(view["max_z_dlas"][i])}
         for key, col in _INFO_FIELDS:
-            spec[key] = _py(np.asarray(quasar_info[col])[i])
+            spec[key] = _py(info[col][i])
         n = int(num_dlas[i])
         spec["dlas"] = [{"log_nhi": _py(map_n[i, n - 1, j]), "z_dla": _py(map_z[i, n - 1, j])}
                         for j in range(n)]                           # :2007-2018
@@ -125,16 +160,20 @@ def generate_json_catalogue(results: dict, quasar_info: dict, outfile: str | Non
     return out
 
 
-def generate_sub_dla_catalogue(results: dict, quasar_info: dict, outfile: str | None = None) -> list:
+def generate_sub_dla_catalogue(results: dict, quasar_info: dict, outfile: str | None = None,
+                               sub_dla: bool = True, occams_razor: float = 10000.0,
+                               drop_nan: bool = True) -> list:
     """``QSOLoader.generate_sub_dla_catalogue`` (qso_loader.py:2033-2087): the quasars whose most
-    probable model is the sub-DLA one, with ``p_sub_dla`` and the spectrum identifiers."""
-    mp = np.asarray(results["model_posteriors"], dtype=np.float64)
-    model_index = np.where(np.isnan(mp), -np.inf, mp).argmax(axis=1)
+    probable model -- after the loader's Occam factor and NaN drop, :func:`loader_view` -- is the
+    sub-DLA one, with ``p_sub_dla`` and the spectrum identifiers."""
+    view, info, _ = loader_view(results, quasar_info, sub_dla, occams_razor, drop_nan)
+    mp = view["model_posteriors"]
+    model_index = np.where(np.isnan(mp), -np.inf, mp).argmax(axis=1)   # dla_map_model_index, :143
     out = []
     for i in np.flatnonzero(model_index == 1):
         rec = {"p_sub_dla": _py(mp[i, 1])}
         for key, col in _INFO_FIELDS:
-            rec[key] = _py(np.asarray(quasar_info[col])[i])
+            rec[key] = _py(info[col][i])
         out.append(rec)
     if outfile is not None:
         import json

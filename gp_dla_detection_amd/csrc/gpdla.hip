@@ -162,10 +162,15 @@ struct gpdla_context {
   bool timing = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_timing = false;
+  // batches uploaded through this context and not yet destroyed.  A batch points back at its
+  // context; destroying the context first orphans them (ctx = nullptr) instead of leaving that
+  // pointer dangling, so gpdla_batch_destroy is safe in either order.
+  std::vector<gpdla_batch *> batches;
 };
 
 struct gpdla_batch {
   gpdla_context *ctx = nullptr;
+  int device_id = 0;
   int64_t nq = 0, S = 0, total_pix = 0;
   int64_t *d_offsets = nullptr;
   double *d_wl = nullptr, *d_flux = nullptr, *d_nv = nullptr, *d_z = nullptr;
@@ -254,6 +259,8 @@ void gpdla_context_destroy(gpdla_context *c) {
   if (!c) return;
   (void)hipSetDevice(c->device_id);
   (void)hipStreamSynchronize(c->stream);
+  for (gpdla_batch *b : c->batches) b->ctx = nullptr;  // orphaned: they only free their memory now
+  c->batches.clear();
   dev_free(c->d_rest);
   dev_free(c->d_mu);
   dev_free(c->d_M);
@@ -382,9 +389,13 @@ double gpdla_context_last_sweep_ms(gpdla_context *c) {
 
 void gpdla_batch_destroy(gpdla_batch *b) {
   if (!b) return;
+  (void)hipSetDevice(b->device_id);
   if (b->ctx) {
-    (void)hipSetDevice(b->ctx->device_id);
     (void)hipStreamSynchronize(b->ctx->stream);
+    auto &v = b->ctx->batches;
+    v.erase(std::remove(v.begin(), v.end(), b), v.end());
+  } else {
+    (void)hipDeviceSynchronize();  // the context (and its stream) went first
   }
   dev_free(b->d_offsets);
   dev_free(b->d_wl);
@@ -425,6 +436,8 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   HIP_TRY(hipSetDevice(c->device_id));
   gpdla_batch *b = new gpdla_batch();
   b->ctx = c;
+  b->device_id = c->device_id;
+  c->batches.push_back(b);
   b->nq = nq;
   b->S = c->S;
   b->k = c->model.k;
@@ -1166,8 +1179,9 @@ struct gpdla_training {
   double *d_x = nullptr, *d_g = nullptr, *d_omega2 = nullptr, *d_f = nullptr;
   int32_t *d_flag = nullptr;
   int64_t x_capacity = 0;
-  // workspace of the matrix-core path (training_mfma_kernels.hpp), allocated for the first k seen
-  int ws_k = 0;
+  // workspace of the matrix-core path (training_mfma_kernels.hpp): its sizes do not depend on k.
+  // ws_ready is set only after every allocation, the stream and the kernel attributes succeeded.
+  bool ws_ready = false;
   double *h_stage = nullptr;  // pinned host staging for x (in) and [g | f | flag] (out)
   int64_t stage_capacity = 0;
   // one evaluation = H2D of x, nine kernels, D2H of [g | f | flag]: captured once per k into a
@@ -1183,20 +1197,44 @@ struct gpdla_training {
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+
+// The captured graph holds raw pointers to d_x, d_g, h_stage and the workspace: it is destroyed
+// BEFORE any of them is freed or replaced, never after.
+void training_drop_graph(gpdla_training *t) {
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  if (t->graph) (void)hipGraphExecDestroy(t->graph);
+  t->graph = nullptr;
+  t->graph_k = 0;
+}
+
+void training_free_workspace(gpdla_training *t) {
+  training_drop_graph(t);
+  for (double **p : {&t->d_wA, &t->d_uA, &t->d_wB, &t->d_uB, &t->d_part1, &t->d_recM, &t->d_recP, &t->d_partB,
+                     &t->d_recD, &t->d_recE, &t->d_nlogp, &t->d_partD, &t->d_partcol, &t->d_partsc, &t->d_scal}) {
+    dev_free(*p);
+    *p = nullptr;
+  }
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  t->stream = nullptr;
+  t->ws_ready = false;
+}
+
+}  // namespace
+
+extern "C" {
+
 void gpdla_training_destroy(gpdla_training *t) {
   if (!t) return;
   (void)hipSetDevice(t->device_id);
   (void)hipDeviceSynchronize();
+  training_free_workspace(t);  // graph, then stream, then the buffers the graph pointed at
   for (void *p : {(void *)t->d_flux, (void *)t->d_lya, (void *)t->d_noise, (void *)t->d_x, (void *)t->d_g,
-                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag, (void *)t->d_loglya, (void *)t->d_wA, (void *)t->d_uA,
-                  (void *)t->d_wB, (void *)t->d_uB, (void *)t->d_part1, (void *)t->d_recM, (void *)t->d_recP,
-                  (void *)t->d_partB, (void *)t->d_recD, (void *)t->d_recE, (void *)t->d_nlogp,
-                  (void *)t->d_partD, (void *)t->d_partcol, (void *)t->d_partsc})
+                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag, (void *)t->d_loglya})
     dev_free(p);
   if (t->h_stage) (void)hipHostFree(t->h_stage);
-  if (t->graph) (void)hipGraphExecDestroy(t->graph);
-  if (t->stream) (void)hipStreamDestroy(t->stream);
-  dev_free(t->d_scal);
   delete t;
 }
 
@@ -1355,8 +1393,10 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
   const TrainDims d = train_dims(t, k);
   const int64_t G = t->G, nx = G * (k + 1) + 3;
   int rc;
-  if (!t->d_wA) {
+  if (!t->ws_ready) {
+    training_free_workspace(t);  // whatever an earlier, failed attempt left behind
     const size_t tiled = (size_t)d.NQ16 * d.T * 64;
+    auto setup = [&]() -> int {
     if ((rc = dev_alloc(&t->d_wA, tiled)) || (rc = dev_alloc(&t->d_uA, tiled)) ||
         (rc = dev_alloc(&t->d_wB, (size_t)d.PG * d.TQ * 64)) || (rc = dev_alloc(&t->d_uB, (size_t)d.PG * d.TQ * 64)) ||
         (rc = dev_alloc(&t->d_part1, (size_t)d.NQ16 * 16 * d.PB * 3)) ||
@@ -1373,10 +1413,16 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrContractLds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_core),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrCoreLds));
+    return GPDLA_OK;
+    };
+    if ((rc = setup())) {
+      training_free_workspace(t);
+      return rc;
+    }
+    t->ws_ready = true;
   }
   if (!t->graph || t->graph_k != k) {  // capture the evaluation once per k
-    if (t->graph) (void)hipGraphExecDestroy(t->graph);
-    t->graph = nullptr;
+    training_drop_graph(t);
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
     rc = training_enqueue_mfma(t, k, t->stream);
@@ -1411,15 +1457,17 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
   const int64_t G = t->G;
   const int64_t nx = G * (k + 1) + 3;
   if (nx > t->x_capacity) {
+    training_drop_graph(t);  // it points at the buffers replaced below
     dev_free(t->d_x);
     dev_free(t->d_g);
     t->d_x = t->d_g = nullptr;
-    int rc;
-    if ((rc = dev_alloc(&t->d_x, (size_t)nx)) || (rc = dev_alloc(&t->d_g, (size_t)nx + 2))) return rc;
-    t->x_capacity = nx;
+    t->x_capacity = 0;
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     t->h_stage = nullptr;
+    int rc;
+    if ((rc = dev_alloc(&t->d_x, (size_t)nx)) || (rc = dev_alloc(&t->d_g, (size_t)nx + 2))) return rc;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&t->h_stage), (size_t)(nx + 2) * sizeof(double), hipHostMallocDefault));
+    t->x_capacity = nx;
   }
   // k <= 20: the three contractions on the matrix cores, ordered (deterministic) sums, one graph
   // launch per evaluation.  GPDLA_TRAIN_LEGACY=1 (diagnostic) or k > 20: one block per quasar,

@@ -359,10 +359,10 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     const bool ok_s = __shfl(chain_ok, sigma) != 0;  // lane sigma (jj = 0) holds sample sigma's flag
     if (writer) {
       if (slot_s < a.S) {
-        if (a.mode == 0) a.sample_ll_lls[q * a.S + slot_s] = ll - a.log_S;                 // multi :376-378
-        else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ok_s ? ll - a.log_S : NAN;  // :359-361
+        if (a.mode == 0) a.sample_ll_lls[q * a.S + slot_s] = ll + m.ll_bias - a.log_S;     // multi :376-378
+        else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ok_s ? ll + m.ll_bias - a.log_S : NAN;  // :359-361
       } else if (slot_s == a.S && a.mode == 1) {
-        a.ll_no_dla[q] = ll;                                                                // multi :296-298
+        a.ll_no_dla[q] = ll + m.ll_bias;                                                    // multi :296-298
       }
     }
   }

@@ -85,11 +85,17 @@ struct QuasarMeta {
   int32_t n_u;       // pixels in the modelled rest range (process_qsos.m:104-108)
   int32_t n_kept;    // of those, not masked (:110)
   int32_t steps;     // ceil(n_u / 4): K-steps of the contraction
-  int32_t status;    // 0 ok, 1 empty
+  int32_t status;    // 0 ok, 1 empty, 3 a kept pixel with noise variance <= 0 or NaN (skipped)
   double min_z_dla;  // :159
   double max_z_dla;  // :160
   int64_t pix_off;   // first row of this quasar in the pixel pools (multiple of 4)
   int64_t lam_off;   // first entry in the padded-wavelength pool
+  // 0, or -inf when a kept pixel has noise variance +inf (a zero inverse variance the mask missed):
+  // log_mvnpdf_low_rank.m:30 then sums log(inf) into the log-determinant and every log-likelihood of
+  // the quasar is -inf.  The sweeps treat that pixel as neutral and add this to each result, so the
+  // K-loop's fast reciprocal never sees an infinite d (it would return NaN where exact division
+  // gives 0).
+  double ll_bias;
 };
 
 struct PixelRow {  // one row of the per-pixel pool, on the unmasked-range grid
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
   __syncthreads();
   double kept_min = INFINITY, kept_max = -INFINITY, un_min = INFINITY, un_max = -INFINITY;
   int kept_count = 0;
+  int nv_flags = 0;  // 1: a kept pixel with noise variance +inf; 2: one with variance <= 0 or NaN
   for (int tile = 0; tile < npix; tile += 256) {
     const int i = tile + tid;
     double wl = 0.0, rest = 0.0;
@@ -203,6 +210,8 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
         kept_max = fmax(kept_max, wl);
         row.y = a.flux[base + i];
         row.nu = a.noise_variance[base + i];
+        if (!(row.nu > 0.0)) nv_flags |= 2;  // the reference's result is undefined (log of d <= 0, 0/0)
+        else if (row.nu == INFINITY) nv_flags |= 1;
         row.mu = a.model.mu[lo] + (a.model.mu[lo + 1] - a.model.mu[lo]) * t;          // :138
         const double lo_om = a.model.log_omega[lo] +
                              (a.model.log_omega[lo + 1] - a.model.log_omega[lo]) * t;  // :141
@@ -239,10 +248,15 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
           row.omega2 = om * (mf * mf);                                                 // multi :293
         }
       }
+      // a kept pixel of infinite variance weighs nothing (1/d = 0) but log d = inf: it is swept as
+      // a neutral row and its effect re-enters through ll_bias (unless its flux is NaN, which the
+      // reference propagates into every result: then the row is left as it is)
+      const bool inf_nv = keep && row.nu == INFINITY && row.y == row.y;
+      if (inf_nv) row = PixelRow{0.0, 0.0, 0.0, 1.0};
       pix[u] = row;
       for (int c = 0; c < k; ++c) {                                                    // :139
         const double m0 = a.model.M[lo + (int64_t)c * G], m1 = a.model.M[lo + 1 + (int64_t)c * G];
-        Mi[(int64_t)u * k + c] = keep ? (m0 + (m1 - m0) * t) * mf : 0.0;  // multi :288
+        Mi[(int64_t)u * k + c] = (keep && !inf_nv) ? (m0 + (m1 - m0) * t) * mf : 0.0;  // multi :288
       }
     }
     __syncthreads();
@@ -261,6 +275,7 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
   kept_max = block_reduce_minmax(kept_max, false, s_red);
   un_min = block_reduce_minmax(un_min, true, s_red);
   un_max = block_reduce_minmax(un_max, false, s_red);
+  nv_flags = __syncthreads_or(nv_flags & 1) | (__syncthreads_or(nv_flags & 2) ? 2 : 0);
   const int steps = (n_u + 3) >> 2;
   // pad rows up to 4*(steps+1): neutral pixels (the last 4 feed the neutral trailing record)
   for (int u = n_u + tid; u < 4 * steps + 4; u += 256) {
@@ -271,7 +286,8 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
     m.n_u = n_u;
     m.n_kept = n_kept;
     m.steps = steps;
-    m.status = (n_kept > 0) ? 0 : 1;
+    m.status = (n_kept > 0) ? ((nv_flags & 2) ? 3 : 0) : 1;
+    m.ll_bias = (nv_flags & 1) ? -INFINITY : 0.0;
     if (n_kept > 0) {
       // set_parameters.m:65-73 on the kept-pixel wavelengths (process_qsos.m:159-160)
       m.max_z_dla = (kept_max / a.cfg.lya_wavelength - 1) - a.cfg.max_z_cut;
@@ -487,7 +503,8 @@ struct SweepArgs {
 };
 
 // 1/a to 2.2e-15 relative: v_rcp_f64 seed (measured 4.6e-8, tools/rcp_accuracy_probe.hip) + ONE
-// Newton step (a is never 0/inf/denormal here).  A second step would make it correctly rounded at
+// Newton step.  a must be finite, non-zero and normal (NaN otherwise): k_prepare keeps non-finite
+// and non-positive noise variances out of the sweeps (QuasarMeta::ll_bias, status 3).  A second step would make it correctly rounded at
 // two more fp64 instructions per use -- two uses per K-step of the sweep, 4 % of its VALU work.
 // What 2e-15 costs: the optical depth moves by 2e-15 relative (absorption by <= 8e-16 absolute),
 // Sum r^2/d by <= 2e-15 |Sum r^2/d| ~ 1e-11..1e-10, log det B by <= k 2e-15: two orders below the
@@ -1364,8 +1381,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
     const int64_t slot_s = slot0 + sigma;
     const int32_t sample_s = __shfl(sample, sigma + 16 * jj);
     if (writer) {
-      if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
-      else if (slot_s == a.S) a.ll_no_dla[q] = ll;
+      if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll + m.ll_bias;
+      else if (slot_s == a.S) a.ll_no_dla[q] = ll + m.ll_bias;
     }
   }
 #ifdef GPDLA_STAMP

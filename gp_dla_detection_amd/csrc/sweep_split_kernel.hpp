@@ -277,8 +277,8 @@ __global__ __launch_bounds__(512) void k_sweep_split(SweepArgs a) {
     const double ll = factor_lds<2, 32>(Eg + (size_t)rho * ncols, lane & 31, a.k, voff, q_s, ld_s, m.n_kept);
     const int64_t slot_s = slot0 + sigma;
     if ((lane & 31) == 0) {
-      if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll;
-      else if (slot_s == a.S) a.ll_no_dla[q] = ll;
+      if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll + m.ll_bias;
+      else if (slot_s == a.S) a.ll_no_dla[q] = ll + m.ll_bias;
     }
   }
 }

@@ -1,5 +1,6 @@
 """Host-side catalogue export (generate_ascii_catalog.m) on synthetic result tables."""
 import numpy as np
+import pytest
 
 from gp_dla_detection_amd import catalog
 
@@ -59,20 +60,76 @@ def test_json_catalogues(tmp_path):
     info = dict(ras=np.arange(nq) * 1.5, decs=-np.arange(nq) * 0.5, plates=np.arange(3586, 3586 + nq),
                 mjds=np.full(nq, 55181), fiber_ids=np.arange(16, 16 + nq), thing_ids=np.arange(1000, 1000 + nq),
                 z_qsos=np.full(nq, 3.6), snrs=np.linspace(1, 4, nq))
-    cat = catalog.generate_json_catalogue(res, info, tmp_path / "predictions_multi_DLAs.json")
+    # occams_razor = 1: the posteriors as saved (the reference's factor is exercised below)
+    cat = catalog.generate_json_catalogue(res, info, tmp_path / "predictions_multi_DLAs.json", occams_razor=1)
     assert [c["num_dlas"] for c in cat] == [0, 0, 2, 1]
-    assert cat[0]["p_no_dla"] == 0.7 + 0.2 and cat[0]["max_model_posterior"] == cat[0]["p_no_dla"]
-    assert cat[1]["max_model_posterior"] == cat[1]["p_no_dla"] == 0.1 + 0.6
-    assert cat[2]["max_model_posterior"] == 0.6
+    approx = lambda v: pytest.approx(v, rel=1e-15, abs=0)
+    assert cat[0]["p_no_dla"] == approx(0.7 + 0.2) and cat[0]["max_model_posterior"] == cat[0]["p_no_dla"]
+    assert cat[1]["max_model_posterior"] == cat[1]["p_no_dla"] == approx(0.1 + 0.6)
+    assert cat[2]["max_model_posterior"] == approx(0.6)
     assert cat[2]["dlas"] == [{"log_nhi": 20.5, "z_dla": 2.5}, {"log_nhi": 21.25, "z_dla": 2.9}]
     assert cat[3]["dlas"] == [{"log_nhi": 20.9, "z_dla": 3.1}] and cat[0]["dlas"] == []
     assert set(cat[0]) == {"p_dla", "p_no_dla", "max_model_posterior", "num_dlas", "dlas", "min_z_dla",
                            "max_z_dla", "ra", "snr", "dec", "plate", "mjd", "fiber_id", "thing_id", "z_qso"}
     back = json.load(open(tmp_path / "predictions_multi_DLAs.json"))
     assert back == cat and isinstance(back[2]["plate"], int)
-    sub = catalog.generate_sub_dla_catalogue(res, info, tmp_path / "sub.json")
-    assert len(sub) == 1 and sub[0]["p_sub_dla"] == 0.6 and sub[0]["thing_id"] == 1001
+    sub = catalog.generate_sub_dla_catalogue(res, info, tmp_path / "sub.json", occams_razor=1)
+    assert len(sub) == 1 and sub[0]["p_sub_dla"] == approx(0.6) and sub[0]["thing_id"] == 1001
     assert set(sub[0]) == {"p_sub_dla", "ra", "snr", "dec", "plate", "mjd", "fiber_id", "thing_id", "z_qso"}
     # without the sub-DLA model the model index IS the number of absorbers minus... (:1973 only)
-    plain = catalog.generate_json_catalogue(res, info, sub_dla=False)
-    assert plain[0]["p_no_dla"] == 0.7 and [c["num_dlas"] for c in plain] == [0, 1, 3, 2]
+    plain = catalog.generate_json_catalogue(res, info, sub_dla=False, occams_razor=1)
+    assert plain[0]["p_no_dla"] == approx(0.7) and [c["num_dlas"] for c in plain] == [0, 1, 3, 2]
+
+
+def test_json_catalogue_applies_the_loaders_occam_factor_and_nan_drop(tmp_path):
+    """the reference's catalogue methods run on QSOLoader's view of the file --
+    _occams_model_posteriors with occams_razor = 10000 (qso_loader.py:136-138, 235-257) and the
+    all-NaN posterior rows dropped (:147-170).  The arithmetic of those lines is restated here
+    independently (in-place division, tiled normalisation, boolean masks) and compared record by
+    record."""
+    import json
+    md, sub = 3, 1
+    mp = np.array([[0.7, 0.2, 0.1, 0.0, 0.0],
+                   [1e-4, 0.3, 0.5, 0.2 - 1e-4, 0.0],
+                   [np.nan] * 5,                         # a quasar the sweep skipped
+                   [1e-7, 0.9, 0.05, 0.05 - 1e-7, 0.0],  # sub-DLA wins even after the penalty
+                   [2e-5, 0.0, 0.2, 0.7, 0.1 - 2e-5]])
+    nq = mp.shape[0]
+    rng = np.random.default_rng(3)
+    map_z, map_n = rng.uniform(2, 3, (nq, md, md)), rng.uniform(20, 22, (nq, md, md))
+    res = dict(model_posteriors=mp, p_dlas=mp[:, 2:].sum(1), p_no_dlas=mp[:, 0].copy(),
+               min_z_dlas=np.linspace(2.0, 2.4, nq), max_z_dlas=np.linspace(3.0, 3.4, nq),
+               MAP_z_dlas=map_z, MAP_log_nhis=map_n)
+    info = dict(ras=np.arange(nq) * 1.5, decs=-np.arange(nq) * 0.5, plates=np.arange(3586, 3586 + nq),
+                mjds=np.full(nq, 55181), fiber_ids=np.arange(16, 16 + nq), thing_ids=np.arange(1000, 1000 + nq),
+                z_qsos=np.full(nq, 3.6), snrs=np.linspace(1, 4, nq))
+    # --- the loader's arithmetic, restated: qso_loader.py:136-170
+    ref = mp.copy()
+    ref[:, 1:] = ref[:, 1:] / 10000                                             # :247
+    norm = np.sum(ref, axis=1)[:, None] * np.ones(ref.shape[1])[None, :]        # :250
+    ref = ref / norm                                                            # :252
+    p_dlas, p_no = ref[:, 1 + sub:].sum(axis=1), ref[:, :1 + sub].sum(axis=1)   # :137-138
+    idx = np.argmax(ref, axis=1)                                                # :143
+    nan = np.isnan(ref[np.arange(nq), idx])                                     # :144-147
+    assert nan.tolist() == [False, False, True, False, False]
+    ref, p_dlas, p_no, idx = ref[~nan], p_dlas[~nan], p_no[~nan], idx[~nan]
+    kept = np.flatnonzero(~nan)
+    num = idx - sub
+    num[num < 0] = 0
+    cat = catalog.generate_json_catalogue(res, info, tmp_path / "c.json")
+    assert len(cat) == 4 and [c["thing_id"] for c in cat] == [1000, 1001, 1003, 1004]
+    for r, c in enumerate(cat):
+        q = kept[r]
+        assert c["p_dla"] == p_dlas[r] and c["p_no_dla"] == p_no[r] and c["num_dlas"] == num[r]
+        top = p_no[r] if idx[r] < 1 + sub else ref[r].max()                      # :1979-1980
+        assert c["max_model_posterior"] == top
+        assert c["min_z_dla"] == res["min_z_dlas"][q] and c["plate"] == 3586 + q
+        assert c["dlas"] == [{"log_nhi": map_n[q, num[r] - 1, j], "z_dla": map_z[q, num[r] - 1, j]}
+                             for j in range(num[r])]
+    assert [c["num_dlas"] for c in cat] == [0, 0, 0, 2]   # 1e-4 vs 0.5e-4: the penalty flips quasar 1 to "no DLA"
+    json.load(open(tmp_path / "c.json"))                  # strict JSON: no NaN record is emitted
+    assert "NaN" not in open(tmp_path / "c.json").read()
+    sub_cat = catalog.generate_sub_dla_catalogue(res, info)
+    assert [s["thing_id"] for s in sub_cat] == [1003] and sub_cat[0]["p_sub_dla"] == ref[2, 1]
+    # the input table is not modified (the reference's helper divides in place)
+    assert mp[0, 1] == 0.2
