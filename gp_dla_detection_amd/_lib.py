@@ -111,6 +111,7 @@ SYMBOLS = [
     ("gpdla_context_set_config", C.c_int, [C.c_void_p, C.POINTER(Config)]),
     ("gpdla_context_synchronize", C.c_int, [C.c_void_p]),
     ("gpdla_batch_upload", C.c_int, [C.c_void_p, C.POINTER(Spectra), C.POINTER(C.c_void_p)]),
+    ("gpdla_batch_reload", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Spectra)]),
     ("gpdla_batch_destroy", None, [C.c_void_p]),
     ("gpdla_batch_process", C.c_int, [C.c_void_p, C.c_void_p]),
     ("gpdla_batch_download", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Results)]),

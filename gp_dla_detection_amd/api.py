@@ -236,6 +236,17 @@ class Batch:
 
     def __init__(self, ctx: Context, spectra, log_priors_no_dla, log_priors_dla, log_priors_lls=None):
         self.ctx = ctx
+        self._h = C.c_void_p()
+        self._fill(spectra, log_priors_no_dla, log_priors_dla, log_priors_lls)
+
+    def reload(self, spectra, log_priors_no_dla, log_priors_dla, log_priors_lls=None):
+        """Replace the batch's spectra in place (gpdla_batch_reload): device allocations are reused
+        where large enough, so the batch slots of a pipeline allocate nothing in the steady state.
+        The previous results must have been downloaded."""
+        self._fill(spectra, log_priors_no_dla, log_priors_dla, log_priors_lls)
+
+    def _fill(self, spectra, log_priors_no_dla, log_priors_dla, log_priors_lls):
+        ctx = self.ctx
         csr = spectra if isinstance(spectra, dict) else spectra_to_csr(spectra)
         self.num_quasars = csr["z_qsos"].size
         self.num_samples = ctx.num_samples
@@ -257,8 +268,10 @@ class Batch:
             ptr(csr["pixel_mask"], np.uint8, C.c_uint8), ptr(csr["z_qsos"], np.float64, C.c_double),
             ptr(log_priors_no_dla, np.float64, C.c_double), ptr(lp_dla, np.float64, C.c_double),
             ptr(log_priors_lls, np.float64, C.c_double) if self.max_dlas else None)
-        self._h = C.c_void_p()
-        _lib.check(ctx.lib.gpdla_batch_upload(ctx._h, C.byref(sp), C.byref(self._h)))
+        if not self._h:
+            _lib.check(ctx.lib.gpdla_batch_upload(ctx._h, C.byref(sp), C.byref(self._h)))
+        else:
+            _lib.check(ctx.lib.gpdla_batch_reload(ctx._h, self._h, C.byref(sp)))
         self.log_priors_no_dla = np.array(log_priors_no_dla, dtype=np.float64)
         self.log_priors_dla = np.array(lp_dla, dtype=np.float64)
         self.log_priors_lls = None if log_priors_lls is None else np.array(log_priors_lls, dtype=np.float64)
@@ -267,26 +280,39 @@ class Batch:
         """Launch the sweep for every quasar of the batch (asynchronous on the context's stream)."""
         _lib.check(self.ctx.lib.gpdla_batch_process(self.ctx._h, self._h))
 
-    def download(self, with_samples: bool = True) -> dict:
-        """Results under the field names process_qsos.m:236-244 saves."""
-        nq, S = self.num_quasars, self.num_samples
-        out = {name: np.full(nq, np.nan) for name in (
-            "min_z_dlas", "max_z_dlas", "log_likelihoods_no_dla", "log_likelihoods_dla",
-            "log_posteriors_no_dla", "log_posteriors_dla", "p_no_dlas", "p_dlas")}
-        for name in ("MAP_inds", "MAP_z_dlas", "MAP_log_nhis"):  # generate_ascii_catalog.m:73-80
-            out[name] = np.full(nq, np.nan)
+    _SINGLE_VECTORS = ("min_z_dlas", "max_z_dlas", "log_likelihoods_no_dla", "log_likelihoods_dla",
+                       "log_posteriors_no_dla", "log_posteriors_dla", "p_no_dlas", "p_dlas",
+                       "MAP_inds", "MAP_z_dlas", "MAP_log_nhis")  # MAP_*: generate_ascii_catalog.m:73-80
+
+    @classmethod
+    def empty_results(cls, nq: int, S: int, with_samples: bool = True) -> dict:
+        """Host arrays for the variables process_qsos.m:236-244 saves, for ``nq`` quasars."""
+        out = {name: np.full(nq, np.nan) for name in cls._SINGLE_VECTORS}
         out["model_posteriors"] = np.full((nq, 2), np.nan)
         out["status"] = np.zeros(nq, dtype=np.int32)
-        if with_samples:
-            out["sample_log_likelihoods_dla"] = np.full((nq, S), np.nan)
+        out["log_priors_no_dla"] = np.full(nq, np.nan)
+        out["log_priors_dla"] = np.full(nq, np.nan)
+        if with_samples:  # every row is written by a download (the device table is NaN-prefilled)
+            out["sample_log_likelihoods_dla"] = np.empty((nq, S))
+        return out
+
+    def download(self, with_samples: bool = True, out: dict | None = None, at: int = 0) -> dict:
+        """Results under the field names process_qsos.m:236-244 saves.  ``out`` / ``at``: write this
+        batch's rows into rows ``at .. at + num_quasars`` of arrays made by :meth:`empty_results`
+        (a pipeline's one set of output arrays) instead of allocating."""
+        nq = self.num_quasars
+        if out is None:
+            out, at = self.empty_results(nq, self.num_samples, with_samples), 0
         r = _lib.Results()
         for name, _ in _lib.Results._fields_:
             if name in out:
                 ct = C.c_int32 if name == "status" else C.c_double
-                setattr(r, name, out[name].ctypes.data_as(C.POINTER(ct)))
+                view = out[name][at:at + nq]
+                assert view.flags.c_contiguous and view.shape[0] == nq
+                setattr(r, name, view.ctypes.data_as(C.POINTER(ct)))
         _lib.check(self.ctx.lib.gpdla_batch_download(self.ctx._h, self._h, C.byref(r)))
-        out["log_priors_no_dla"] = self.log_priors_no_dla
-        out["log_priors_dla"] = self.log_priors_dla
+        out["log_priors_no_dla"][at:at + nq] = self.log_priors_no_dla
+        out["log_priors_dla"][at:at + nq] = self.log_priors_dla
         return out
 
     def summary_tensor(self):
@@ -321,10 +347,9 @@ class Batch:
             base_ptr = base.ctypes.data_as(C.POINTER(C.c_uint32))
         _lib.check(self.ctx.lib.gpdla_batch_process_multi(self.ctx._h, self._h, base_ptr))
 
-    def download_multi(self, with_samples: bool = True) -> dict:
-        """Results under the variable names the multi-DLA script saves (:498-510); 3-D arrays are
-        ``sample_log_likelihoods_dla [nq, max_dlas, S]`` and ``MAP_* [nq, model, slot]``."""
-        nq, md, S = self.num_quasars, self.max_dlas, self.num_samples
+    @staticmethod
+    def empty_results_multi(nq: int, md: int, S: int, with_samples: bool = True) -> dict:
+        """Host arrays for the variables the multi-DLA script saves (:498-510), for ``nq`` quasars."""
         out = {
             "min_z_dlas": np.full(nq, np.nan), "max_z_dlas": np.full(nq, np.nan),
             "log_likelihoods_no_dla": np.full(nq, np.nan),
@@ -336,22 +361,34 @@ class Batch:
             "MAP_z_dlas": np.full((nq, md, md), np.nan), "MAP_log_nhis": np.full((nq, md, md), np.nan),
             "MAP_inds": np.full((nq, md, md), np.nan),
             "status": np.zeros(nq, dtype=np.int32),
+            "log_priors_no_dla": np.full(nq, np.nan), "log_priors_lls": np.full(nq, np.nan),
+            "log_priors_dla": np.full((nq, md), np.nan), "all_exceptions": np.full(nq, np.nan),
         }
         if with_samples:
-            out["sample_log_likelihoods_dla"] = np.full((nq, md, S), np.nan)
-            out["sample_log_likelihoods_lls"] = np.full((nq, S), np.nan)
-            out["base_sample_inds"] = np.zeros((nq, max(md - 1, 1), S), dtype=np.uint32)
+            out["sample_log_likelihoods_dla"] = np.empty((nq, md, S))
+            out["sample_log_likelihoods_lls"] = np.empty((nq, S))
+            out["base_sample_inds"] = np.zeros((nq, md - 1, S), dtype=np.uint32)
+        return out
+
+    def download_multi(self, with_samples: bool = True, out: dict | None = None, at: int = 0) -> dict:
+        """Results under the variable names the multi-DLA script saves (:498-510); 3-D arrays are
+        ``sample_log_likelihoods_dla [nq, max_dlas, S]`` and ``MAP_* [nq, model, slot]``.
+        ``out`` / ``at``: as in :meth:`download`."""
+        nq, md, S = self.num_quasars, self.max_dlas, self.num_samples
+        if out is None:
+            out, at = self.empty_results_multi(nq, md, S, with_samples), 0
         r = _lib.ResultsMulti()
         for name, _ in _lib.ResultsMulti._fields_:
-            if name in out:
+            if name in out and out[name].size:
                 ct = {"status": C.c_int32, "base_sample_inds": C.c_uint32}.get(name, C.c_double)
-                setattr(r, name, out[name].ctypes.data_as(C.POINTER(ct)))
+                view = out[name][at:at + nq]
+                assert view.flags.c_contiguous and view.shape[0] == nq
+                setattr(r, name, view.ctypes.data_as(C.POINTER(ct)))
         _lib.check(self.ctx.lib.gpdla_batch_download_multi(self.ctx._h, self._h, C.byref(r)))
-        out["log_priors_no_dla"], out["log_priors_lls"], out["log_priors_dla"] = (
-            self.log_priors_no_dla, self.log_priors_lls, self.log_priors_dla)
-        out["all_exceptions"] = np.where(out["status"] == 1, 1.0, np.nan)  # multi :139, :232
-        if with_samples and md > 1:
-            out["base_sample_inds"] = out["base_sample_inds"][:, : md - 1]
+        out["log_priors_no_dla"][at:at + nq] = self.log_priors_no_dla
+        out["log_priors_lls"][at:at + nq] = self.log_priors_lls
+        out["log_priors_dla"][at:at + nq] = self.log_priors_dla
+        out["all_exceptions"][at:at + nq] = np.where(out["status"][at:at + nq] == 1, 1.0, np.nan)  # multi :139, :232
         return out
 
     def samples_multi_tensors(self):
@@ -390,48 +427,113 @@ class Batch:
 # the script surface
 # ----------------------------------------------------------------------------------------------
 
+def record_bytes_per_quasar(num_pixels: int, k: int) -> int:
+    """HBM a quasar of ``num_pixels`` stored pixels occupies in a resident batch: its step records
+    (one per 4 pixels; record_doubles() in csrc/sweep_kernels.hpp: 14 tiles x 64 + 64 doubles for
+    k <= 20, 56 x 64 + 128 for k <= 40) plus the interpolated rows (k + 4 doubles per pixel)."""
+    per_step = (14 * 64 + 64) if k <= 20 else (56 * 64 + 128)
+    return int((num_pixels / 4 + 2) * per_step * 8 + (num_pixels + 8) * (k + 6) * 8)
+
+
+def default_batch_size(num_quasars: int, longest: int, k: int, num_samples: int, slots: int,
+                       budget_bytes: float = 96 * 2**30, multi_models: int = 0) -> int:
+    """Quasars per batch of the host pipeline: small enough that ``slots`` batches (records + result
+    tables) fit ``budget_bytes`` of HBM and that a run has ~8 batches to overlap (the first upload
+    and the last download are the only copies not hidden behind a sweep), at least 128 so that a
+    launch fills the 256 CUs many times over."""
+    per_q = record_bytes_per_quasar(longest, k) + 8 * num_samples * max(1, 2 * multi_models)
+    cap = max(1, int(budget_bytes / slots / per_q))
+    want = max(128, -(-num_quasars // 8))
+    return max(1, min(cap, want, 4096))
+
+
+def run_pipeline(ctx: "Context", num_blocks: int, inputs, process, download, slots: int = 3):
+    """The host loop of process_qsos.m:88 as a three-stage pipeline over HBM-resident batches:
+    while batch i is swept, batch i+1 is prepared and uploaded by one thread and batch i-1
+    downloaded by another (the library's copy streams run beside the compute stream; ctypes
+    releases the GIL inside the calls).  ``inputs(i)`` returns the arguments of ``Context.upload``
+    for block i; ``process(i, batch)`` launches its sweep (main thread, in order);
+    ``download(i, batch)`` fetches its results.  ``slots`` batches exist at a time and are
+    re-filled in place, so the steady state allocates nothing."""
+    from concurrent.futures import ThreadPoolExecutor
+    if num_blocks <= 0:
+        return
+    slots = max(1, min(slots, num_blocks))
+    batches = [None] * slots
+    done = [None] * num_blocks
+    up_pool, down_pool = ThreadPoolExecutor(1), ThreadPoolExecutor(1)
+
+    def upload(i):
+        slot = i % slots
+        if i >= slots:
+            done[i - slots].result()  # the slot's previous results are on the host
+        args = inputs(i)
+        if batches[slot] is None:
+            batches[slot] = ctx.upload(*args)
+        else:
+            batches[slot].reload(*args)
+        return batches[slot]
+
+    try:
+        nxt = up_pool.submit(upload, 0)
+        for i in range(num_blocks):
+            batch = nxt.result()
+            if i + 1 < num_blocks:
+                nxt = up_pool.submit(upload, i + 1)
+            process(i, batch)
+            done[i] = down_pool.submit(download, i, batch)
+        for f in done:
+            f.result()
+    finally:
+        up_pool.shutdown(wait=True)
+        down_pool.shutdown(wait=True)
+        for b in batches:
+            if b is not None:
+                b.close()
+
+
 def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None = None,
                  params: Parameters | None = None, device: int = 0,
-                 log_priors: tuple | None = None, max_quasars_per_batch: int | None = None) -> dict:
+                 log_priors: tuple | None = None, max_quasars_per_batch: int | None = None,
+                 pipeline_slots: int = 3, with_samples: bool = True) -> dict:
     """The ``process_qsos`` script (process_qsos.m:4-250) for a list of quasars.
 
     ``spectra``: list of dicts with ``wavelengths, flux, noise_variance, pixel_mask, z_qso`` (one
     entry of the ``all_*`` cell arrays each, after the ``test_ind`` subset of :56-61).
     ``prior_catalog``: ``{"z_qsos", "dla_ind"}`` of the training release after the Lyman-limit
     filter of :15-25; or pass ``log_priors=(log_priors_no_dla, log_priors_dla)`` directly.
-    Quasars are independent, so a long list is swept in HBM-resident batches of at most
-    ``max_quasars_per_batch`` (default: sized to ~64 GiB of step records).
+    Quasars are independent, so the list is swept in HBM-resident batches of at most
+    ``max_quasars_per_batch`` (default: :func:`default_batch_size`) through :func:`run_pipeline`:
+    uploads and downloads overlap the sweeps.  Results do not depend on the batching.
     Returns the variables the script saves (:236-244)."""
     p = params or Parameters()
     spectra = list(spectra)
+    nq = len(spectra)
     z_all = np.array([float(s["z_qso"]) for s in spectra], dtype=np.float64)
     if log_priors is None:
         if prior_catalog is None:
             raise ValueError("need prior_catalog or log_priors")
         log_priors = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], z_all, p)
     lp_no, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
+    S = np.asarray(samples["offset_samples"]).size
+    k = np.asarray(model["M"]).shape[1]
     if max_quasars_per_batch is None:
         longest = max((np.asarray(s["wavelengths"]).size for s in spectra), default=1)
-        per_quasar = (longest / 4 + 2) * (14 * 64 + 48) * 8  # bytes of step records (k <= 20)
-        if model["M"].shape[1] > 20:
-            per_quasar *= 3.9  # (56 * 64 + 32) / (14 * 64 + 48)
-        max_quasars_per_batch = max(1, int(64 * 2**30 / per_quasar))
+        max_quasars_per_batch = default_batch_size(nq, longest, k, S, pipeline_slots)
+    blocks = [(lo, min(lo + max_quasars_per_batch, nq)) for lo in range(0, nq, max_quasars_per_batch)]
+    out = Batch.empty_results(nq, S, with_samples) if nq else {}
     ctx = Context(device, p)
-    parts = []
     try:
         ctx.set_model(model)
         ctx.set_samples(samples)
-        for lo in range(0, len(spectra), max_quasars_per_batch):
-            hi = min(lo + max_quasars_per_batch, len(spectra))
-            batch = ctx.upload(spectra[lo:hi], lp_no[lo:hi], lp_dla[lo:hi])
-            try:
-                batch.process()
-                parts.append(batch.download())
-            finally:
-                batch.close()
+        run_pipeline(ctx, len(blocks),
+                     lambda i: (spectra[blocks[i][0]:blocks[i][1]], lp_no[blocks[i][0]:blocks[i][1]],
+                                lp_dla[blocks[i][0]:blocks[i][1]]),
+                     lambda i, batch: batch.process(),
+                     lambda i, batch: batch.download(with_samples, out, blocks[i][0]),
+                     pipeline_slots)
     finally:
         ctx.close()
-    out = {key: np.concatenate([part[key] for part in parts], axis=0) for key in parts[0]} if parts else {}
     out["num_lines"] = p.num_lines
     out["prior_z_qso_increase"] = p.prior_z_qso_increase
     out["max_z_cut"] = p.max_z_cut
@@ -467,7 +569,8 @@ def dla_existence_prior_multi(prior_z_qsos, prior_dla_ind, z_qsos, Z_lls: float,
 def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log_priors,
                                         params: MultiParameters | None = None,
                                         base_sample_inds=None, device: int = 0,
-                                        max_quasars_per_batch: int | None = None) -> dict:
+                                        max_quasars_per_batch: int | None = None,
+                                        pipeline_slots: int = 3) -> dict:
     """The multi-DLA driver (multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-510).
 
     ``samples`` additionally carries ``log_nhi_samples`` and ``lls_nhi_samples``
@@ -483,18 +586,21 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
     ``sample_log_likelihoods_dla [nq, max_dlas, S]`` and ``MAP_* [nq, model, slot]``."""
     from dataclasses import replace
     p = params or MultiParameters()
-    spectra = list(spectra) if not isinstance(spectra, dict) else spectra
-    if isinstance(spectra, dict):  # CSR in: one batch
-        nq = spectra["z_qsos"].size
-        blocks = [(0, nq, spectra)]
-    else:
-        nq = len(spectra)
-        if max_quasars_per_batch is None:
-            max_quasars_per_batch = max(1, nq)
-        blocks = [(lo, min(lo + max_quasars_per_batch, nq), spectra[lo:lo + max_quasars_per_batch])
-                  for lo in range(0, nq, max_quasars_per_batch)]
     md = p.max_dlas
     S = np.asarray(samples["offset_samples"]).size
+    if isinstance(spectra, dict):  # CSR in: one batch
+        nq = spectra["z_qsos"].size
+        blocks = [(0, nq)]
+        take = lambda lo, hi: spectra
+    else:
+        spectra = list(spectra)
+        nq = len(spectra)
+        if max_quasars_per_batch is None:
+            longest = max((np.asarray(s["wavelengths"]).size for s in spectra), default=1)
+            max_quasars_per_batch = default_batch_size(nq, longest, np.asarray(model["M"]).shape[1], S,
+                                                       pipeline_slots, multi_models=md + 1)
+        blocks = [(lo, min(lo + max_quasars_per_batch, nq)) for lo in range(0, nq, max_quasars_per_batch)]
+        take = lambda lo, hi: spectra[lo:hi]
     lp_no, lp_lls, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
     lp_dla = lp_dla.reshape(nq, md)
     if base_sample_inds is not None:
@@ -502,20 +608,22 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
         if base_sample_inds.shape != (nq, md - 1, S):
             raise _lib.GpdlaError(-1, "base_sample_inds must be [nq, max_dlas-1, S], got "
                                   f"{base_sample_inds.shape}")
+    out = Batch.empty_results_multi(nq, md, S) if nq else {}
     ctx = Context(device, p)
-    parts = []
+
+    def process(i, batch):
+        lo, hi = blocks[i]
+        ctx.set_params(replace(p, first_quasar_index=p.first_quasar_index + lo))
+        batch.process_multi(None if base_sample_inds is None else base_sample_inds[lo:hi])
+
     try:
         ctx.set_model(model)
         ctx.set_samples(samples)
-        for lo, hi, block in blocks:
-            if lo:
-                ctx.set_params(replace(p, first_quasar_index=p.first_quasar_index + lo))
-            batch = ctx.upload(block, lp_no[lo:hi], lp_dla[lo:hi], lp_lls[lo:hi])
-            try:
-                batch.process_multi(None if base_sample_inds is None else base_sample_inds[lo:hi])
-                parts.append(batch.download_multi())
-            finally:
-                batch.close()
+        run_pipeline(ctx, len(blocks),
+                     lambda i: (take(*blocks[i]), lp_no[blocks[i][0]:blocks[i][1]],
+                                lp_dla[blocks[i][0]:blocks[i][1]], lp_lls[blocks[i][0]:blocks[i][1]]),
+                     process, lambda i, batch: batch.download_multi(True, out, blocks[i][0]),
+                     pipeline_slots)
     finally:
         ctx.close()
-    return {key: np.concatenate([part[key] for part in parts], axis=0) for key in parts[0]} if parts else {}
+    return out

@@ -148,6 +148,12 @@ struct gpdla_context {
   int device_id = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // Copy streams: uploads and downloads run beside a sweep in flight on `stream`, so a host
+  // pipeline can upload batch i+1 and download batch i-1 while batch i is swept (one thread each:
+  // the entry points of ONE context may be called concurrently as long as each batch is touched
+  // by one thread at a time).
+  hipStream_t up_stream = nullptr, down_stream = nullptr;
+  std::mutex mu;  // guards `batches`
   // model
   bool has_model = false;
   ModelDev model{};
@@ -171,6 +177,14 @@ struct gpdla_context {
 struct gpdla_batch {
   gpdla_context *ctx = nullptr;
   int device_id = 0;
+  hipEvent_t ev_done = nullptr;  // recorded on the compute stream behind the last kernel of a process call
+  // capacities (elements) of the device arrays below: gpdla_batch_reload re-fills a batch in
+  // place and reallocates only what has grown, so a pipeline's batch slots do no hipMalloc/hipFree
+  // (hipFree waits for the whole device) in the steady state
+  struct {
+    size_t offsets = 0, wl = 0, flux = 0, nv = 0, z = 0, mask = 0, lp_no = 0, lp_dla = 0, meta = 0, order = 0,
+           pix = 0, Mi = 0, lam = 0, records = 0, sample_ll = 0, ll_no = 0, summary = 0;
+  } cap;
   int64_t nq = 0, S = 0, total_pix = 0;
   int64_t *d_offsets = nullptr;
   double *d_wl = nullptr, *d_flux = nullptr, *d_nv = nullptr, *d_z = nullptr;
@@ -248,7 +262,13 @@ int gpdla_context_create(int device_id, gpdla_context **out) {
   if (rc) return rc;
   gpdla_context *c = new gpdla_context();
   c->device_id = device_id;
-  HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    gpdla_context_destroy(c);
+    return fail(GPDLA_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+  }
   c->stream = c->own_stream;
   gpdla_default_config(&c->cfg);
   *out = c;
@@ -258,9 +278,14 @@ int gpdla_context_create(int device_id, gpdla_context **out) {
 void gpdla_context_destroy(gpdla_context *c) {
   if (!c) return;
   (void)hipSetDevice(c->device_id);
-  (void)hipStreamSynchronize(c->stream);
-  for (gpdla_batch *b : c->batches) b->ctx = nullptr;  // orphaned: they only free their memory now
-  c->batches.clear();
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+  if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    for (gpdla_batch *b : c->batches) b->ctx = nullptr;  // orphaned: they only free their memory now
+    c->batches.clear();
+  }
   dev_free(c->d_rest);
   dev_free(c->d_mu);
   dev_free(c->d_M);
@@ -273,6 +298,8 @@ void gpdla_context_destroy(gpdla_context *c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+  if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
   delete c;
 }
 
@@ -298,6 +325,8 @@ int gpdla_context_synchronize(gpdla_context *c) {
   if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
   HIP_TRY(hipSetDevice(c->device_id));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(c->up_stream));
+  HIP_TRY(hipStreamSynchronize(c->down_stream));
   return GPDLA_OK;
 }
 
@@ -392,11 +421,15 @@ void gpdla_batch_destroy(gpdla_batch *b) {
   (void)hipSetDevice(b->device_id);
   if (b->ctx) {
     (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipStreamSynchronize(b->ctx->up_stream);
+    (void)hipStreamSynchronize(b->ctx->down_stream);
+    std::lock_guard<std::mutex> lock(b->ctx->mu);
     auto &v = b->ctx->batches;
     v.erase(std::remove(v.begin(), v.end(), b), v.end());
   } else {
-    (void)hipDeviceSynchronize();  // the context (and its stream) went first
+    (void)hipDeviceSynchronize();  // the context (and its streams) went first
   }
+  if (b->ev_done) (void)hipEventDestroy(b->ev_done);
   dev_free(b->d_offsets);
   dev_free(b->d_wl);
   dev_free(b->d_flux);
@@ -418,26 +451,51 @@ void gpdla_batch_destroy(gpdla_batch *b) {
   delete b;
 }
 
-int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **out) {
-  if (!c || !sp || !out) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
-  *out = nullptr;
+}  // extern "C"
+
+namespace {
+
+// (re)allocate *p for `count` elements unless its capacity already suffices
+template <typename T>
+int reserve(T **p, size_t *cap, size_t count) {
+  if (count == 0) count = 1;
+  if (*p && *cap >= count) return GPDLA_OK;
+  dev_free(*p);
+  *p = nullptr;
+  *cap = 0;
+  int rc = dev_alloc(p, count);
+  if (!rc) *cap = count;
+  return rc;
+}
+
+template <typename T>
+int reserve_copy(T **p, size_t *cap, const T *host, size_t count, hipStream_t st) {
+  int rc = reserve(p, cap, count);
+  if (rc) return rc;
+  if (count) HIP_TRY(hipMemcpyAsync(*p, host, count * sizeof(T), hipMemcpyHostToDevice, st));
+  return GPDLA_OK;
+}
+
+int validate_spectra(gpdla_context *c, const gpdla_spectra *sp, int *md_out) {
   if (!c->has_model || !c->has_samples)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "set the model and the samples before uploading spectra");
   if (sp->num_quasars < 1 || !sp->offsets || !sp->wavelengths || !sp->flux || !sp->noise_variance ||
       !sp->pixel_mask || !sp->z_qsos || !sp->log_priors_no_dla || !sp->log_priors_dla)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
-  const int64_t nq = sp->num_quasars;
   const int md = sp->log_priors_lls ? c->cfg.max_dlas : 0;
   if (sp->log_priors_lls && (md < 1 || md > 4))
     return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d outside [1, 4]", md);
-  for (int64_t q = 0; q < nq; ++q)
+  for (int64_t q = 0; q < sp->num_quasars; ++q)
     if (sp->offsets[q + 1] < sp->offsets[q])
       return fail(GPDLA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing (quasar %lld)", (long long)q);
-  HIP_TRY(hipSetDevice(c->device_id));
-  gpdla_batch *b = new gpdla_batch();
-  b->ctx = c;
-  b->device_id = c->device_id;
-  c->batches.push_back(b);
+  *md_out = md;
+  return GPDLA_OK;
+}
+
+// Fill batch b (new or being reloaded) from host spectra: H2D on the context's upload stream, which
+// is drained before returning (the caller's buffers and the host vectors here are consumed).
+int batch_fill(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, int md) {
+  const int64_t nq = sp->num_quasars;
   b->nq = nq;
   b->S = c->S;
   b->k = c->model.k;
@@ -446,6 +504,7 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   b->ntiles = b->k <= 20 ? kCompactTiles : 56;
   const int64_t base = sp->offsets[0];
   b->total_pix = sp->offsets[nq] - base;
+  b->max_pix = 0;
   std::vector<int64_t> off(nq + 1);
   std::vector<QuasarMeta> meta(nq);
   int64_t rows = 0, lam = 0;
@@ -461,51 +520,92 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
     b->max_pix = std::max(b->max_pix, npix);
   }
   b->pool_rows = rows;
+  if (b->md != md) {  // (reload with a different kind of batch)
+    delete b->mb;
+    b->mb = nullptr;
+  }
   b->md = md;
-  hipStream_t st = c->stream;
+  hipStream_t st = c->up_stream;
+  StreamDrain drain{st};  // on every exit: nothing still reads off / meta / order / the caller's arrays
   int rc = GPDLA_OK;
   auto chk = [&](int r) { if (r && !rc) rc = r; };
-  chk(upload(&b->d_offsets, off.data(), (size_t)nq + 1, st));
-  chk(upload(&b->d_wl, sp->wavelengths + base, (size_t)b->total_pix, st));
-  chk(upload(&b->d_flux, sp->flux + base, (size_t)b->total_pix, st));
-  chk(upload(&b->d_nv, sp->noise_variance + base, (size_t)b->total_pix, st));
-  chk(upload(&b->d_mask, sp->pixel_mask + base, (size_t)b->total_pix, st));
-  chk(upload(&b->d_z, sp->z_qsos, (size_t)nq, st));
-  chk(upload(&b->d_lp_no, sp->log_priors_no_dla, (size_t)nq, st));
+  chk(reserve_copy(&b->d_offsets, &b->cap.offsets, off.data(), (size_t)nq + 1, st));
+  chk(reserve_copy(&b->d_wl, &b->cap.wl, sp->wavelengths + base, (size_t)b->total_pix, st));
+  chk(reserve_copy(&b->d_flux, &b->cap.flux, sp->flux + base, (size_t)b->total_pix, st));
+  chk(reserve_copy(&b->d_nv, &b->cap.nv, sp->noise_variance + base, (size_t)b->total_pix, st));
+  chk(reserve_copy(&b->d_mask, &b->cap.mask, sp->pixel_mask + base, (size_t)b->total_pix, st));
+  chk(reserve_copy(&b->d_z, &b->cap.z, sp->z_qsos, (size_t)nq, st));
+  chk(reserve_copy(&b->d_lp_no, &b->cap.lp_no, sp->log_priors_no_dla, (size_t)nq, st));
   if (!md) {
-    chk(upload(&b->d_lp_dla, sp->log_priors_dla, (size_t)nq, st));
+    chk(reserve_copy(&b->d_lp_dla, &b->cap.lp_dla, sp->log_priors_dla, (size_t)nq, st));
   } else {  // multi-DLA batch: [nq][max_dlas] DLA priors + the sub-DLA prior (multi :204-210)
+    delete b->mb;  // result tables are sized by nq: rebuilt by the next gpdla_batch_process_multi
     b->mb = new MultiBuffers();
     chk(upload(&b->mb->lp_dla, sp->log_priors_dla, (size_t)nq * md, st));
     chk(upload(&b->mb->lp_lls, sp->log_priors_lls, (size_t)nq, st));
   }
-  chk(upload(&b->d_meta, meta.data(), (size_t)nq, st));
+  chk(reserve_copy(&b->d_meta, &b->cap.meta, meta.data(), (size_t)nq, st));
   std::vector<int32_t> order((size_t)nq);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
     return off[x + 1] - off[x] > off[y + 1] - off[y];
   });
-  chk(upload(&b->d_order, order.data(), (size_t)nq, st));
-  chk(dev_alloc(&b->d_pix, (size_t)rows));
-  chk(dev_alloc(&b->d_Mi, (size_t)rows * b->k));
-  chk(dev_alloc(&b->d_lam, (size_t)lam));
-  chk(dev_alloc(&b->d_records, (size_t)(rows / 4 + kRecordPoolPad) * record_doubles(b->ntiles, 0)));
+  chk(reserve_copy(&b->d_order, &b->cap.order, order.data(), (size_t)nq, st));
+  chk(reserve(&b->d_pix, &b->cap.pix, (size_t)rows));
+  chk(reserve(&b->d_Mi, &b->cap.Mi, (size_t)rows * b->k));
+  chk(reserve(&b->d_lam, &b->cap.lam, (size_t)lam));
+  chk(reserve(&b->d_records, &b->cap.records, (size_t)(rows / 4 + kRecordPoolPad) * record_doubles(b->ntiles, 0)));
   if (!md) {
-    chk(dev_alloc(&b->d_sample_ll, (size_t)nq * b->S));
-    chk(dev_alloc(&b->d_ll_no, (size_t)nq));
-    chk(dev_alloc(&b->d_summary, (size_t)nq * GPDLA_SUMMARY_COLS));
+    chk(reserve(&b->d_sample_ll, &b->cap.sample_ll, (size_t)nq * b->S));
+    chk(reserve(&b->d_ll_no, &b->cap.ll_no, (size_t)nq));
+    chk(reserve(&b->d_summary, &b->cap.summary, (size_t)nq * GPDLA_SUMMARY_COLS));
   }
-  if (rc) {
+  if (rc) return rc;
+  if (hipStreamSynchronize(st) != hipSuccess) return fail(GPDLA_ERR_HIP, "upload synchronize failed");
+  return GPDLA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **out) {
+  if (!c || !sp || !out) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  int md = 0;
+  int rc = validate_spectra(c, sp, &md);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device_id));
+  gpdla_batch *b = new gpdla_batch();
+  b->ctx = c;
+  b->device_id = c->device_id;
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->batches.push_back(b);
+  }
+  if (hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess) {
+    gpdla_batch_destroy(b);
+    return fail(GPDLA_ERR_HIP, "hipEventCreateWithFlags failed");
+  }
+  if ((rc = batch_fill(c, b, sp, md))) {
     gpdla_batch_destroy(b);
     return rc;
   }
-  // host vectors (off, meta) must outlive the async copies
-  if (hipStreamSynchronize(st) != hipSuccess) {
-    gpdla_batch_destroy(b);
-    return fail(GPDLA_ERR_HIP, "upload synchronize failed");
-  }
   *out = b;
   return GPDLA_OK;
+}
+
+int gpdla_batch_reload(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp) {
+  if (!c || !b || !sp || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
+  int md = 0;
+  int rc = validate_spectra(c, sp, &md);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device_id));
+  // the batch's previous sweep (if any) must have finished reading what is overwritten here; its
+  // download is the caller's to have completed (gpdla.h)
+  HIP_TRY(hipEventSynchronize(b->ev_done));
+  HIP_TRY(hipStreamSynchronize(c->down_stream));
+  return batch_fill(c, b, sp, md);  // on failure the batch stays valid to destroy, not to process
 }
 
 }  // extern "C"
@@ -690,6 +790,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   ea.summary = b->d_summary;
   hipLaunchKernelGGL(k_evidence, dim3((unsigned)b->nq), dim3(256), 0, st, ea);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(b->ev_done, st));
   return GPDLA_OK;
 }
 
@@ -717,14 +818,18 @@ int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) {
   const size_t nq = (size_t)b->nq;
   std::vector<double> summary(nq * GPDLA_SUMMARY_COLS);
   std::vector<QuasarMeta> meta(nq);
-  StreamDrain drain{c->stream};
+  // on the download stream, behind this batch's last kernel: a sweep of ANOTHER batch that is in
+  // flight on the compute stream is not waited for
+  hipStream_t ds = c->down_stream;
+  StreamDrain drain{ds};
+  HIP_TRY(hipStreamWaitEvent(ds, b->ev_done, 0));
   HIP_TRY(hipMemcpyAsync(summary.data(), b->d_summary, summary.size() * sizeof(double),
-                         hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(meta.data(), b->d_meta, nq * sizeof(QuasarMeta), hipMemcpyDeviceToHost, c->stream));
+                         hipMemcpyDeviceToHost, ds));
+  HIP_TRY(hipMemcpyAsync(meta.data(), b->d_meta, nq * sizeof(QuasarMeta), hipMemcpyDeviceToHost, ds));
   if (r->sample_log_likelihoods_dla)
     HIP_TRY(hipMemcpyAsync(r->sample_log_likelihoods_dla, b->d_sample_ll, nq * b->S * sizeof(double),
-                           hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+                           hipMemcpyDeviceToHost, ds));
+  HIP_TRY(hipStreamSynchronize(ds));
   for (size_t q = 0; q < nq; ++q) {
     const double *s = &summary[q * GPDLA_SUMMARY_COLS];
     if (r->min_z_dlas) r->min_z_dlas[q] = s[0];
@@ -1071,6 +1176,7 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
     HIP_TRY(hipEventRecord(c->ev1, st));
     c->have_timing = true;
   }
+  HIP_TRY(hipEventRecord(b->ev_done, st));
   mb.processed = true;
   return GPDLA_OK;
 }
@@ -1081,7 +1187,7 @@ int gpdla_batch_download_multi(gpdla_context *c, gpdla_batch *b, gpdla_results_m
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "no multi-DLA results: call gpdla_batch_process_multi first");
   HIP_TRY(hipSetDevice(c->device_id));
   MultiBuffers &mb = *b->mb;
-  hipStream_t st = c->stream;
+  hipStream_t st = c->down_stream;  // behind this batch's last kernel, beside other batches' sweeps
   const size_t nqs = (size_t)b->nq, S = (size_t)b->S;
   const int md = b->md;
   const size_t nbase = nqs * (md > 1 ? md - 1 : 0) * S;
@@ -1089,6 +1195,7 @@ int gpdla_batch_download_multi(gpdla_context *c, gpdla_batch *b, gpdla_results_m
   auto chk = [&](int x) { if (x && !rc) rc = x; };
   std::vector<QuasarMeta> meta(nqs);
   StreamDrain drain{st};  // (also covers the caller's arrays: nothing is in flight once this returns)
+  HIP_TRY(hipStreamWaitEvent(st, b->ev_done, 0));
   HIP_TRY(hipMemcpyAsync(meta.data(), b->d_meta, nqs * sizeof(QuasarMeta), hipMemcpyDeviceToHost, st));
   auto dl = [&](void *dst, const void *src, size_t bytes) -> int {
     if (dst && bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));

@@ -265,6 +265,58 @@ def load_preloaded_qsos(path: str, z_qsos, test_ind=None) -> list:
                  z_qso=float(z[i])) for j, i in enumerate(idx)]
 
 
+class PreloadedReader:
+    """Random access to the ragged cell arrays of a ``-v7.3`` preloaded_qsos.mat (preload_qsos.m:64-79):
+    the file is opened once, the four reference tables are read, and a rank then dereferences only
+    the quasars of its own block -- pixel counts come from the dataset headers alone, so sharding a
+    run by pixel count (distributed.shard_bounds) reads no spectrum."""
+
+    KEYS = ("all_wavelengths", "all_flux", "all_noise_variance", "all_pixel_mask")
+
+    def __init__(self, path: str):
+        if not _is_hdf5(path):
+            raise ValueError(f"{path}: not a -v7.3 file (use load_preloaded_qsos for -v7 files)")
+        self.path = path
+        self._f = hdf5.File(path)
+        self._refs = {}
+        for k in self.KEYS:
+            if k not in self._f:
+                self._f.close()
+                raise KeyError(f"{path} lacks {k}")
+            self._refs[k] = self._f[k].read().T.ravel(order="F")
+        self.num_quasars = int(self._refs[self.KEYS[0]].size)
+
+    def pixel_counts(self, indices=None) -> np.ndarray:
+        """Stored pixels per quasar (``numel(all_wavelengths{i})``) for the 0-based ``indices``."""
+        idx = np.arange(self.num_quasars) if indices is None else np.asarray(indices)
+        refs = self._refs["all_wavelengths"]
+        return np.array([int(np.prod(self._f.dereference(refs[i]).shape)) for i in idx], dtype=np.int64)
+
+    def read(self, indices, z_qsos) -> list:
+        """Per-quasar dicts (as :func:`load_preloaded_qsos` returns) for the 0-based ``indices``;
+        ``z_qsos``: the catalogue's redshift column for ALL quasars of the file."""
+        z = _vec(z_qsos)
+        if z.size != self.num_quasars:
+            raise ValueError(f"{self.num_quasars} spectra but {z.size} redshifts")
+        out = []
+        for i in np.asarray(indices):
+            cell = {k: _from_dataset(self._f, self._f.dereference(self._refs[k][i])) for k in self.KEYS}
+            out.append(dict(wavelengths=_vec(cell["all_wavelengths"]), flux=_vec(cell["all_flux"]),
+                            noise_variance=_vec(cell["all_noise_variance"]),
+                            pixel_mask=np.asarray(cell["all_pixel_mask"]).reshape(-1).astype(np.uint8),
+                            z_qso=float(z[i])))
+        return out
+
+    def close(self):
+        self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # outputs of the path
 # ---------------------------------------------------------------------------------------------
@@ -367,3 +419,71 @@ def load_processed_qsos(path: str) -> dict:
                 v = np.transpose(v, (0, 2, 1))
         out[k] = v
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# chunk files of a sharded run (CDDF_analysis/sbatch_reunion.py:13-63)
+# ---------------------------------------------------------------------------------------------
+
+def chunk_filename(directory: str, test_set_name: str, lo: int, hi: int, multi: bool = False,
+                   width: int = 6) -> str:
+    """Name of the chunk holding quasars [lo, hi) (0-based positions within the run's ``test_ind``
+    selection) of a sharded run: the reference's output name (process_qsos.m:246-248; multi
+    :512-521) followed by the zero-padded range, so that sorting the names orders the chunks the
+    way ``mat_combine`` must be handed them."""
+    stem = f"processed_qsos_multi_meanflux{test_set_name}" if multi else f"processed_qsos_{test_set_name}"
+    return f"{directory}/{stem}_{lo:0{width}d}-{hi:0{width}d}.mat"
+
+
+def combine_processed_chunks(paths, out_path: str, test_ind=None) -> None:
+    """What ``mat_combine`` (CDDF_analysis/sbatch_reunion.py:13-63) does -- every variable whose
+    quasar axis has the first chunk's length is concatenated along that axis, everything else is
+    taken from the first chunk -- written as a MATLAB ``-v7.3`` file and streamed, so that the
+    13 GB sample table of a DR12Q run is never held in memory (the reference's script peaks at
+    ~150 GB, sbatch_reunion.py:6-7).  ``test_ind``: the combined run's selection; by default the
+    OR of the chunks' own masks (``mat_combine`` keeps the first chunk's, which then selects only
+    that chunk's quasars)."""
+    paths = list(paths)
+    files = [hdf5.File(p) for p in paths]
+    try:
+        first = files[0]
+        names = [k for k in first.keys() if not k.startswith("#")]
+        sizes = []
+        for f in files:
+            sizes.append(int(f["p_dlas"].shape[-1]))
+        w = hdf5.FileWriter(out_path, userblock=matlab_userblock())
+        try:
+            for name in names:
+                ds = first[name]
+                attrs = {k: v for k, v in ds.attrs.items()}
+                if name == "test_ind":
+                    mask = test_ind
+                    if mask is None:
+                        mask = np.zeros(ds.shape, dtype=bool)
+                        for f in files:
+                            mask |= f["test_ind"].read().astype(bool)
+                    w.create_dataset(name, np.asarray(mask, dtype=np.uint8).reshape(ds.shape), attrs=attrs)
+                    continue
+                per_quasar = len(ds.shape) >= 1 and ds.shape[-1] == sizes[0] and all(
+                    name in f and f[name].shape[:-1] == ds.shape[:-1] and f[name].shape[-1] == n
+                    for f, n in zip(files, sizes))
+                if not per_quasar or "MATLAB_empty" in attrs:
+                    w.create_dataset(name, ds.read(), attrs=attrs)
+                    continue
+                total = sum(sizes)
+                shape = ds.shape[:-1] + (total,)
+                if len(shape) == 1:
+                    w.create_dataset(name, np.concatenate([f[name].read() for f in files]), attrs=attrs)
+                    continue
+                maps = [f[name].read(memmap=True) for f in files]
+                row_bytes = int(np.prod(shape[1:])) * ds.dtype.itemsize
+                step = max(1, (256 << 20) // max(row_bytes, 1))
+                w.create_dataset_streamed(
+                    name, shape, ds.dtype,
+                    (np.concatenate([m[i:i + step] for m in maps], axis=-1) for i in range(0, shape[0], step)),
+                    attrs=attrs)
+        finally:
+            w.close()
+    finally:
+        for f in files:
+            f.close()

@@ -1,0 +1,216 @@
+"""File-to-file sharded run: BASELINE config 3 (DR12Q on the 8 GPUs of a node) as a pipeline.
+
+The reference processes a catalogue by running ``process_qsos`` on disjoint ``test_ind`` slices as
+separate batch jobs, each saving its own ``processed_qsos_*.mat``, and recombining the chunks
+afterwards with ``mat_combine`` (CDDF_analysis/sbatch_reunion.py:13-63).  Here the jobs are the
+ranks of one ``torch.distributed`` process group, one per GPU:
+
+1. every rank opens the ``-v7.3`` inputs of process_qsos.m:30-61 (catalogue, learned model, DLA
+   samples, preloaded spectra) and takes the run's ``test_ind`` selection (:52-61);
+2. the selected quasars are split into contiguous blocks balanced by pixel count
+   (:func:`distributed.shard_bounds`; the counts come from dataset headers, no spectrum is read);
+3. a rank sweeps its block in bounded HBM-resident batches through :func:`api.run_pipeline` -- the
+   spectra of batch i+1 are read from the file and uploaded, and the results of batch i-1
+   downloaded, while batch i is swept;
+4. each rank writes its own chunk ``processed_qsos_<name>_<lo>-<hi>.mat`` (single-DLA variables of
+   process_qsos.m:236-250, or the multi-DLA list of multi :498-523) with the chunk's own
+   ``test_ind`` -- a file the reference's ``mat_combine`` recombines unchanged
+   (tests/golden/make_consumer_fixtures.py does exactly that);
+5. the per-quasar posterior rows (15 or 78 fp64) are all-gathered over RCCL, so every rank -- and
+   rank 0's ``*_summary.mat`` -- holds the whole run's posterior table; the per-sample tables stay
+   in the chunks, as the reference keeps them per job.
+
+Launch: ``python -m torch.distributed.run --nproc-per-node 8 -m gp_dla_detection_amd.run_dr12q ...``
+or call :func:`run` from a process whose default group is initialised (world 1 needs no group).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from dataclasses import replace
+
+import numpy as np
+
+from . import _lib, io
+from .api import (Batch, Context, default_batch_size, dla_existence_prior, dla_existence_prior_multi,
+                  run_pipeline)
+from .distributed import (_world, gather_summaries, shard_bounds, summary_to_fields,
+                          summary_to_fields_multi)
+from .parameters import MultiParameters, Parameters
+
+
+def select_test_ind(catalog: dict, test_ind=None) -> np.ndarray:
+    """0-based catalogue indices of the run: ``test_ind`` as a boolean mask / index array, or the
+    reference's default selection ``catalog.filter_flags == 0`` (README.md:296)."""
+    n = np.asarray(catalog["z_qsos"]).size
+    if test_ind is None:
+        flags = catalog.get("filter_flags")
+        return np.arange(n) if flags is None else np.flatnonzero(np.asarray(flags).reshape(-1) == 0)
+    t = np.asarray(test_ind).reshape(-1)
+    if t.dtype == bool:
+        if t.size != n:
+            raise ValueError(f"test_ind has {t.size} entries for {n} catalogue quasars")
+        return np.flatnonzero(t)
+    return t.astype(np.int64)
+
+
+def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file: str, out_dir: str,
+        test_set_name: str = "dr12q", test_ind=None, prior_catalog: dict | None = None,
+        multi: bool = False, params: Parameters | None = None, Z_lls: float | None = None,
+        Z_dla: float | None = None, device: int | None = None, max_quasars_per_batch: int | None = None,
+        pipeline_slots: int = 3, run_metadata: dict | None = None, write_summary: bool = True) -> dict:
+    """One rank of the sharded file-to-file run (see the module docstring).
+
+    ``prior_catalog``: ``{"z_qsos", "dla_ind"}`` of the training release (``api.prepare_prior``);
+    multi-DLA runs also need ``Z_lls`` / ``Z_dla`` (set_lls_parameters.m:59-71).
+    Returns ``dict(fields=<posterior variables of ALL quasars of the run>, block=(lo, hi),
+    chunk=<path of this rank's chunk file or None>, selected=<catalogue indices of the run>)``."""
+    import torch
+
+    world, rank = _world()
+    p = params or (MultiParameters() if multi else Parameters())
+    if device is None:
+        device = torch.cuda.current_device()
+    if prior_catalog is None:
+        raise ValueError("need prior_catalog (z_qsos, dla_ind of the training release)")
+    catalog = io.load_catalog(catalog_file)
+    z_all = np.asarray(catalog["z_qsos"], dtype=np.float64).reshape(-1)
+    sel = select_test_ind(catalog, test_ind)
+    model = io.load_learned_model(learned_file)
+    samples = io.load_dla_samples(samples_file)
+    S, k = samples["offset_samples"].size, model["M"].shape[1]
+    os.makedirs(out_dir, exist_ok=True)
+    reader = io.PreloadedReader(preloaded_file)
+    try:
+        if reader.num_quasars != z_all.size:
+            raise ValueError(f"{preloaded_file} holds {reader.num_quasars} spectra, the catalogue {z_all.size}")
+        counts = reader.pixel_counts(sel)
+        bounds = shard_bounds(counts, world)
+        lo, hi = bounds[rank]
+        nloc = hi - lo
+        z_sel = z_all[sel]
+        if multi:
+            if Z_lls is None or Z_dla is None:
+                raise ValueError("a multi-DLA run needs Z_lls and Z_dla (set_lls_parameters.m:59-71)")
+            lp_no, lp_lls, lp_dla = dla_existence_prior_multi(prior_catalog["z_qsos"], prior_catalog["dla_ind"],
+                                                              z_sel[lo:hi], Z_lls, Z_dla, p)
+            ncol = _lib.summary_cols_multi(p.max_dlas)
+        else:
+            lp_no, lp_dla = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], z_sel[lo:hi], p)
+            lp_lls = None
+            ncol = _lib.SUMMARY_COLS
+        # the rank's posterior table lives on the GPU: each batch's rows are copied into it behind
+        # its sweep (same stream), and the whole table is what the RCCL all-gather reads
+        stream = torch.cuda.Stream(device=device)
+        table = torch.empty((nloc, ncol), dtype=torch.float64, device=f"cuda:{device}")
+        local = None
+        if nloc:
+            if max_quasars_per_batch is None:
+                max_quasars_per_batch = default_batch_size(nloc, int(counts[lo:hi].max()), k, S, pipeline_slots,
+                                                           multi_models=(p.max_dlas + 1) if multi else 0)
+            blocks = [(b, min(b + max_quasars_per_batch, nloc)) for b in range(0, nloc, max_quasars_per_batch)]
+            local = (Batch.empty_results_multi(nloc, p.max_dlas, S) if multi else Batch.empty_results(nloc, S))
+            ctx = Context(device, p, stream=stream)
+
+            def inputs(i):  # runs on the upload thread: file reads overlap the sweep in flight
+                b0, b1 = blocks[i]
+                spectra = reader.read(sel[lo + b0:lo + b1], z_all)
+                args = (spectra, lp_no[b0:b1], lp_dla[b0:b1])
+                return args + ((lp_lls[b0:b1],) if multi else ())
+
+            def process(i, batch):
+                b0, b1 = blocks[i]
+                with torch.cuda.stream(stream):
+                    if multi:
+                        ctx.set_params(replace(p, first_quasar_index=p.first_quasar_index + lo + b0))
+                        batch.process_multi()
+                    else:
+                        batch.process()
+                    table[b0:b1].copy_(batch.summary_tensor())
+
+            def download(i, batch):
+                b0, _ = blocks[i]
+                (batch.download_multi(True, local, b0) if multi else batch.download(True, local, b0))
+
+            try:
+                ctx.set_model(model)
+                ctx.set_samples(samples)
+                run_pipeline(ctx, len(blocks), inputs, process, download, pipeline_slots)
+                stream.synchronize()
+            finally:
+                ctx.close()
+    finally:
+        reader.close()
+
+    chunk = None
+    if nloc:
+        chunk = io.chunk_filename(out_dir, test_set_name, lo, hi, multi)
+        mask = np.zeros(z_all.size, dtype=bool)
+        mask[sel[lo:hi]] = True
+        meta = dict(test_set_name=test_set_name, **(run_metadata or {}))
+        local.update(num_lines=p.num_lines, prior_z_qso_increase=p.prior_z_qso_increase, max_z_cut=p.max_z_cut)
+        if multi:
+            local.update(k=k, min_z_cut=p.min_z_cut, num_dla_samples=S)
+            io.save_processed_qsos_multi(chunk, local, test_ind=mask, **meta)
+        else:
+            io.save_processed_qsos(chunk, local, test_ind=mask, **meta)
+
+    with torch.cuda.stream(stream):
+        gathered = gather_summaries(table, [b[1] - b[0] for b in bounds])
+    stream.synchronize()
+    fields = summary_to_fields_multi(gathered, p.max_dlas) if multi else summary_to_fields(gathered)
+    if write_summary and rank == 0:
+        mask = np.zeros(z_all.size, dtype=bool)
+        mask[sel] = True
+        stem = f"processed_qsos_multi_meanflux{test_set_name}" if multi else f"processed_qsos_{test_set_name}"
+        io.savemat73(os.path.join(out_dir, stem + "_summary.mat"),
+                     dict(test_ind=mask.reshape(-1, 1), **{k_: v for k_, v in fields.items()}))
+    return dict(fields=fields, block=(lo, hi), chunk=chunk, selected=sel)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--preloaded", required=True, help="preloaded_qsos.mat (-v7.3)")
+    ap.add_argument("--catalog", required=True, help="catalog.mat")
+    ap.add_argument("--learned", required=True, help="learned_qso_model_*.mat")
+    ap.add_argument("--samples", required=True, help="dla_samples.mat")
+    ap.add_argument("--prior", required=True,
+                    help=".mat/.npz with the training release's z_qsos and dla_ind (after api.prepare_prior)")
+    ap.add_argument("--out", required=True, help="output directory for the chunk files")
+    ap.add_argument("--name", default="dr12q", help="test_set_name")
+    ap.add_argument("--multi", action="store_true", help="multi-DLA driver (process_qsos_multiple_dlas_meanflux)")
+    ap.add_argument("--z-lls", type=float, default=None)
+    ap.add_argument("--z-dla", type=float, default=None)
+    ap.add_argument("--max-dlas", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=None, help="quasars per HBM-resident batch")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    args = ap.parse_args(argv)
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        kw = dict(device_id=torch.device("cuda", local_rank)) if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, **kw)
+    try:
+        if args.prior.endswith(".npz"):
+            pr = np.load(args.prior)
+            prior = dict(z_qsos=pr["z_qsos"], dla_ind=pr["dla_ind"])
+        else:
+            m = io._load_mat(args.prior, ("z_qsos", "dla_ind"))
+            prior = dict(z_qsos=np.asarray(m["z_qsos"]).reshape(-1), dla_ind=np.asarray(m["dla_ind"]).reshape(-1) != 0)
+        params = MultiParameters(max_dlas=args.max_dlas) if args.multi else Parameters()
+        res = run(args.preloaded, args.catalog, args.learned, args.samples, args.out, args.name,
+                  prior_catalog=prior, multi=args.multi, params=params, Z_lls=args.z_lls, Z_dla=args.z_dla,
+                  device=local_rank, max_quasars_per_batch=args.batch)
+        print(f"rank {int(os.environ.get('RANK', '0'))}: quasars [{res['block'][0]}, {res['block'][1]}) -> {res['chunk']}",
+              flush=True)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -188,3 +188,67 @@ def make_prior_catalog(num: int = 5000, seed: int = 777) -> dict:
     z_qsos = rng.uniform(2.15, 5.0, size=num)
     dla_ind = rng.uniform(size=num) < 0.1
     return dict(z_qsos=z_qsos, dla_ind=dla_ind)
+
+
+def write_file_set(directory: str, num_quasars: int = 24, num_samples: int = 256, k: int = 20,
+                   skip_every: int = 5, first_index: int = 4000, empty_quasar: int | None = 7) -> dict:
+    """A small, seeded stand-in for the files either side of the path, with MATLAB's conventions
+    (``-v7.3``, column vectors, cell arrays, logical masks): ``catalog.mat`` (build_catalogs.m:86-91:
+    the plain per-quasar columns), ``preloaded_qsos.mat`` (preload_qsos.m:64-79),
+    ``learned_qso_model_synthetic.mat`` (learn_qso_model.m:113-123), ``dla_samples.mat``
+    (generate_dla_samples.m:59-63 + set_lls_parameters.m:59-63), ``snrs_qsos.mat``, the training
+    release's ``prior_catalog.npz`` and the two text catalogues ``QSOLoader`` opens
+    (qso_loader.py:410-424: ``dla_catalog`` = thing_id, z_dla, log_nhi; ``los_catalog`` = thing_id).
+    Every ``skip_every``-th quasar has ``filter_flags != 0`` (outside ``test_ind``); quasar
+    ``empty_quasar`` is fully masked (the sweep skips it: NaN results).  Returns the paths and
+    the arrays behind them."""
+    import os
+
+    from . import io
+    os.makedirs(directory, exist_ok=True)
+    d = str(directory)
+    model = make_model(k)
+    samples = make_samples(num_samples)
+    spectra = make_dr12q_mix(num_quasars, model, first_index=first_index)
+    if empty_quasar is not None and empty_quasar < num_quasars:
+        s = spectra[empty_quasar]
+        s["pixel_mask"] = np.ones_like(s["pixel_mask"])
+        s["flux"] = np.full_like(s["flux"], np.nan)
+        s["noise_variance"] = np.full_like(s["noise_variance"], np.inf)
+    rng = np.random.default_rng(99)
+    col = lambda a, dt=np.float64: np.asarray(a, dtype=dt).reshape(-1, 1)
+    filter_flags = np.array([(i % skip_every == skip_every - 1) * 2 for i in range(num_quasars)], dtype=np.uint8)
+    cat = dict(z_qsos=np.array([s["z_qso"] for s in spectra]), thing_ids=100000 + 7 * np.arange(num_quasars),
+               plates=3586 + np.arange(num_quasars) // 4, mjds=55181 + np.arange(num_quasars) % 3,
+               fiber_ids=1 + np.arange(num_quasars), snrs=rng.uniform(0.5, 12.0, num_quasars),
+               ras=rng.uniform(0, 360, num_quasars), decs=rng.uniform(-10, 60, num_quasars),
+               filter_flags=filter_flags)
+    paths = dict(catalog=f"{d}/catalog.mat", preloaded=f"{d}/preloaded_qsos.mat",
+                 learned=f"{d}/learned_qso_model_synthetic.mat", samples=f"{d}/dla_samples.mat",
+                 snrs=f"{d}/snrs_qsos.mat", prior=f"{d}/prior_catalog.npz",
+                 dla_catalog=f"{d}/dla_catalog", los_catalog=f"{d}/los_catalog")
+    io.savemat73(paths["catalog"], {k_: col(v, np.uint8 if k_ == "filter_flags" else np.float64)
+                                    for k_, v in cat.items()})
+    cells = {}
+    for key, src in (("all_wavelengths", "wavelengths"), ("all_flux", "flux"),
+                     ("all_noise_variance", "noise_variance"), ("all_pixel_mask", "pixel_mask")):
+        cells[key] = [np.asarray(s[src]).astype(bool if src == "pixel_mask" else np.float64).reshape(-1, 1)
+                      for s in spectra]
+    io.savemat73(paths["preloaded"], cells, compress=True)
+    io.savemat73(paths["learned"], {k_: (col(v) if np.ndim(v) == 1 else v) for k_, v in model.items()},
+                 compress=True)
+    io.savemat73(paths["samples"], {k_: v.reshape(1, -1) for k_, v in samples.items()})
+    io.savemat73(paths["snrs"], dict(snrs=col(cat["snrs"])))
+    prior = make_prior_catalog()
+    np.savez(paths["prior"], **prior)
+    test_ind = filter_flags == 0
+    # a "concordance" catalogue naming the injected absorbers of some searched quasars
+    with open(paths["dla_catalog"], "w") as f:
+        for i, s in enumerate(spectra):
+            if test_ind[i] and s["true_z_dla"] is not None and i % 3 == 1:
+                f.write("%d %.6f %.4f\n" % (cat["thing_ids"][i], s["true_z_dla"], s["true_log_nhi"]))
+    with open(paths["los_catalog"], "w") as f:
+        for i in np.flatnonzero(test_ind):
+            f.write("%d\n" % cat["thing_ids"][i])
+    return dict(paths=paths, model=model, samples=samples, spectra=spectra, catalog=cat, prior=prior,
+                test_ind=test_ind, Z_lls=0.31, Z_dla=0.69)

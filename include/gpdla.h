@@ -38,7 +38,7 @@ typedef enum {
 } gpdla_status;
 
 #define GPDLA_MAX_K 40
-#define GPDLA_ABI_VERSION 2
+#define GPDLA_ABI_VERSION 3
 
 int gpdla_abi_version(void);
 /* Human-readable text of the most recent error on this thread (never NULL). */
@@ -148,7 +148,8 @@ typedef struct {
   double *model_posteriors;           /* [nq][2] = (no DLA, DLA) */
   double *p_no_dlas;                  /* [nq] */
   double *p_dlas;                     /* [nq] */
-  int32_t *status;                    /* [nq] 0 ok, 1 = empty spectrum (multi: all_exceptions, :232) */
+  int32_t *status;                    /* [nq] 0 ok, 1 = empty spectrum (multi: all_exceptions, :232),
+                                         3 = a kept pixel with noise variance <= 0 or NaN (skipped) */
   /* generate_ascii_catalog.m:73-80, found by the evidence kernel while it walks the table anyway:
    * [~, map_ind] = nanmax(sample_log_likelihoods_dla(i, :)) (1-based, first index on ties; 1 for an
    * all-NaN row, as MATLAB returns), map_z_dla = min_z + (max_z - min_z) * offset_samples(map_ind),
@@ -185,6 +186,13 @@ int gpdla_context_synchronize(gpdla_context *ctx);
  * [nq][max_dlas] (max_dlas of the context's config at this call) and the batch is processed with
  * gpdla_batch_process_multi. */
 int gpdla_batch_upload(gpdla_context *ctx, const gpdla_spectra *spectra, gpdla_batch **batch);
+/* Re-fills an existing batch with another set of spectra (any size, same or other kind), reusing
+ * its device allocations where they are large enough: the batch slots of a host pipeline -- the
+ * loop process_qsos.m:88 runs serially -- do no allocation in the steady state.  The batch's
+ * previous results must have been downloaded (or be no longer wanted). */
+int gpdla_batch_reload(gpdla_context *ctx, gpdla_batch *batch, const gpdla_spectra *spectra);
+/* Safe in either order with gpdla_context_destroy (a batch whose context went first only frees
+ * its memory). */
 void gpdla_batch_destroy(gpdla_batch *batch);
 
 /* The hot path: selection + interpolation (process_qsos.m:102-146), null evidence (:149-151),
@@ -192,7 +200,12 @@ void gpdla_batch_destroy(gpdla_batch *batch);
  * quasar of the batch.  Asynchronous on the context's stream; results stay in HBM. */
 int gpdla_batch_process(gpdla_context *ctx, gpdla_batch *batch);
 
-/* D2H copy of the batch's results (synchronises the stream). */
+/* D2H copy of the batch's results; returns when they are in the caller's arrays.  Uploads,
+ * reloads and downloads run on the context's own copy streams, ordered against the batch's own
+ * sweep by events: they do not wait for a sweep of ANOTHER batch in flight on the compute stream,
+ * so a host pipeline can upload batch i+1 and download batch i-1 while batch i is swept.  The
+ * entry points of one context may be called from several threads as long as each batch is used
+ * by one thread at a time. */
 int gpdla_batch_download(gpdla_context *ctx, gpdla_batch *batch, gpdla_results *results);
 
 /* Device pointer to the per-quasar summary table of the batch, [nq][GPDLA_SUMMARY_COLS] doubles:

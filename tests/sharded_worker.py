@@ -102,3 +102,34 @@ def run_rccl_world1(port, out_dir):
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def run_files_rank(rank, world, port, multi, in_dir, out_dir, per_batch):
+    """One rank of the file-to-file run (gp_dla_detection_amd.run_dr12q.run) on cuda:0 over gloo:
+    reads the synthetic file set in ``in_dir`` (synthetic.write_file_set), writes its chunk file
+    into ``out_dir`` and saves what it returned."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from gp_dla_detection_amd import run_dr12q
+    from gp_dla_detection_amd.parameters import MultiParameters
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pr = np.load(os.path.join(in_dir, "prior_catalog.npz"))
+        res = run_dr12q.run(os.path.join(in_dir, "preloaded_qsos.mat"), os.path.join(in_dir, "catalog.mat"),
+                            os.path.join(in_dir, "learned_qso_model_synthetic.mat"),
+                            os.path.join(in_dir, "dla_samples.mat"), out_dir, "synth",
+                            prior_catalog=dict(z_qsos=pr["z_qsos"], dla_ind=pr["dla_ind"]), multi=multi,
+                            params=MultiParameters(max_dlas=3) if multi else None, Z_lls=0.31, Z_dla=0.69,
+                            device=0, max_quasars_per_batch=per_batch,
+                            run_metadata=dict(release="dr12q", training_release="dr12q",
+                                              training_set_name="synthetic"))
+        np.savez(os.path.join(out_dir, f"files_{'multi' if multi else 'single'}_w{world}_r{rank}.npz"),
+                 block=np.array(res["block"]), chunk=np.array(res["chunk"] or ""), selected=res["selected"],
+                 **{"f_" + k: v for k, v in res["fields"].items()})
+    finally:
+        if world > 1:
+            dist.destroy_process_group()

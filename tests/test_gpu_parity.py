@@ -410,14 +410,75 @@ def test_bad_pixels_in_kept_data_propagate_like_the_reference(oracle, model20):
 
 
 def test_chunked_driver_matches_single_batch(model20):
-    """process_qsos splits a long quasar list into memory-bounded batches; results are identical."""
+    """process_qsos sweeps a long quasar list in bounded batches through the upload / sweep /
+    download pipeline (api.run_pipeline); results are identical whatever the batching and the
+    number of batch slots -- ragged sizes, so re-filled slots both reuse and grow their buffers."""
     samples = synthetic.make_samples(64)
-    spectra = synthetic.make_spectra(7, 260, model20, first_index=470)
-    lp = flat_priors(7)
-    one = gp.process_qsos(model20, samples, spectra, log_priors=lp)
-    many = gp.process_qsos(model20, samples, spectra, log_priors=lp, max_quasars_per_batch=3)
-    for key in ("sample_log_likelihoods_dla", "log_likelihoods_dla", "model_posteriors", "status"):
-        np.testing.assert_array_equal(one[key], many[key])
+    spectra = [synthetic.make_spectrum(470 + i, n, model20, mask_fraction=0.03)
+               for i, n in enumerate([260, 120, 410, 90, 333, 505, 64, 280, 199, 620, 75])]
+    lp = flat_priors(len(spectra))
+    one = gp.process_qsos(model20, samples, spectra, log_priors=lp, max_quasars_per_batch=len(spectra))
+    for per_batch, slots in ((3, 3), (2, 2), (1, 1), (4, 2), (5, 3)):
+        many = gp.process_qsos(model20, samples, spectra, log_priors=lp, max_quasars_per_batch=per_batch,
+                               pipeline_slots=slots)
+        for key in one:
+            np.testing.assert_array_equal(one[key], many[key], err_msg=f"{key} {per_batch} {slots}")
+    default = gp.process_qsos(model20, samples, spectra, log_priors=lp)
+    np.testing.assert_array_equal(one["sample_log_likelihoods_dla"], default["sample_log_likelihoods_dla"])
+
+
+def test_batch_reload_and_destroy_order(model20):
+    """gpdla_batch_reload re-fills a batch in place; a batch may outlive its context (it is
+    orphaned, not left with a dangling pointer); using it then is an error, destroying it is not."""
+    samples = synthetic.make_samples(48)
+    a = synthetic.make_spectra(3, 300, model20, first_index=610)
+    b = synthetic.make_spectra(5, 180, model20, first_index=620)
+    ctx = gp.Context(0)
+    ctx.set_model(model20)
+    ctx.set_samples(samples)
+    batch = ctx.upload(a, *flat_priors(3))
+    batch.process()
+    ra = batch.download()
+    batch.reload(b, *flat_priors(5))      # more quasars, fewer pixels
+    batch.process()
+    rb = batch.download()
+    batch.reload(a, *flat_priors(3))
+    batch.process()
+    ra2 = batch.download()
+    for key in ra:
+        np.testing.assert_array_equal(ra[key], ra2[key], err_msg=key)
+    fresh = gp.process_qsos(model20, samples, b, log_priors=flat_priors(5))
+    np.testing.assert_array_equal(rb["sample_log_likelihoods_dla"], fresh["sample_log_likelihoods_dla"])
+    ctx.close()                           # context first ...
+    with pytest.raises(Exception):
+        batch.process()
+    batch.close()                         # ... batch afterwards: only frees its memory
+
+
+def test_noise_variance_guards(model20, oracle):
+    """A kept pixel of infinite noise variance (a zero inverse variance the mask missed): the
+    reference sums log(inf) into the log-determinant (log_mvnpdf_low_rank.m:30), so every
+    log-likelihood of that quasar is -inf and the evidences follow (process_qsos.m:203-213) -- the
+    oracle does exactly that.  A kept pixel with variance <= 0 or NaN has no defined result in the
+    reference; here the quasar is skipped with status 3."""
+    samples = synthetic.make_samples(40)
+    sp = synthetic.make_spectra(3, 240, model20, first_index=640)
+    sp[0]["noise_variance"] = sp[0]["noise_variance"].copy()
+    sp[0]["noise_variance"][57] = np.inf
+    sp[2]["noise_variance"] = sp[2]["noise_variance"].copy()
+    sp[2]["noise_variance"][100] = -1e-3
+    out = gp.process_qsos(model20, samples, sp, log_priors=flat_priors(3))
+    assert out["status"].tolist() == [0, 0, 3]
+    ref = oracle.process_spectrum(model20, samples["offset_samples"], samples["nhi_samples"], sp[0]["wavelengths"],
+                                  sp[0]["flux"], sp[0]["noise_variance"], sp[0]["pixel_mask"], sp[0]["z_qso"])
+    assert np.all(np.isneginf(ref["sample_log_likelihoods_dla"])) and np.isneginf(ref["log_likelihood_no_dla"])
+    assert np.all(np.isneginf(out["sample_log_likelihoods_dla"][0])) and np.isneginf(out["log_likelihoods_no_dla"][0])
+    assert np.isnan(out["log_likelihoods_dla"][0]) and np.isnan(ref["log_likelihood_dla"])
+    assert out["MAP_inds"][0] == 1
+    ok = oracle.process_spectrum(model20, samples["offset_samples"], samples["nhi_samples"], sp[1]["wavelengths"],
+                                 sp[1]["flux"], sp[1]["noise_variance"], sp[1]["pixel_mask"], sp[1]["z_qso"])
+    assert np.abs(out["sample_log_likelihoods_dla"][1] - ok["sample_log_likelihoods_dla"]).max() < TOL
+    assert np.all(np.isnan(out["sample_log_likelihoods_dla"][2])) and np.isnan(out["p_dlas"][2])
 
 
 def test_randomised_shapes_vs_oracle(oracle):

@@ -101,6 +101,7 @@ def test_multi_dla_run_to_v73_and_json(files):
     assert json.load(open(d / "predictions_multi_DLAs.json")) == json.loads(json.dumps(recs))
     for r, mp in zip(recs, out["model_posteriors"]):
         assert 0 <= r["num_dlas"] <= 3 and len(r["dlas"]) == r["num_dlas"]
-        assert abs(r["p_no_dla"] - (mp[0] + mp[1])) < 1e-12
+        occ = catalog.occams_model_posteriors(mp[None, :])[0]  # the loader's Occam factor (qso_loader.py:136)
+        assert abs(r["p_no_dla"] - (occ[0] + occ[1])) < 1e-12
         for dla in r["dlas"]:
             assert r["min_z_dla"] <= dla["z_dla"] <= r["max_z_dla"] and 20.0 <= dla["log_nhi"] <= 23.0

@@ -1,0 +1,103 @@
+"""Host pieces of the file-to-file sharded run (gp_dla_detection_amd/run_dr12q.py) that need no GPU:
+the synthetic file set, header-only pixel counts, chunk naming, and the streamed recombination of
+chunk files -- the reference's mat_combine (CDDF_analysis/sbatch_reunion.py:13-63) restated."""
+import numpy as np
+import pytest
+
+from gp_dla_detection_amd import hdf5, io, run_dr12q, synthetic
+from gp_dla_detection_amd.api import Batch, default_batch_size, record_bytes_per_quasar
+
+
+@pytest.fixture(scope="module")
+def fileset(tmp_path_factory):
+    return synthetic.write_file_set(str(tmp_path_factory.mktemp("fileset")), num_quasars=12, num_samples=64)
+
+
+def test_file_set_reads_back(fileset):
+    fs = fileset
+    cat = io.load_catalog(fs["paths"]["catalog"])
+    np.testing.assert_array_equal(cat["z_qsos"], fs["catalog"]["z_qsos"])
+    sel = run_dr12q.select_test_ind(cat)
+    np.testing.assert_array_equal(sel, np.flatnonzero(fs["test_ind"]))
+    np.testing.assert_array_equal(run_dr12q.select_test_ind(cat, fs["test_ind"]), sel)
+    np.testing.assert_array_equal(run_dr12q.select_test_ind(cat, [3, 1]), [3, 1])
+    with io.PreloadedReader(fs["paths"]["preloaded"]) as r:
+        assert r.num_quasars == 12
+        counts = r.pixel_counts(sel)
+        np.testing.assert_array_equal(counts, [fs["spectra"][i]["wavelengths"].size for i in sel])
+        got = r.read(sel[2:5], cat["z_qsos"])
+    for g, i in zip(got, sel[2:5]):
+        s = fs["spectra"][i]
+        np.testing.assert_array_equal(g["wavelengths"], s["wavelengths"])
+        np.testing.assert_array_equal(g["flux"], s["flux"])
+        np.testing.assert_array_equal(g["pixel_mask"], s["pixel_mask"])
+        assert g["z_qso"] == s["z_qso"]
+    m = io.load_learned_model(fs["paths"]["learned"])
+    np.testing.assert_array_equal(m["M"], fs["model"]["M"])
+    smp = io.load_dla_samples(fs["paths"]["samples"])
+    np.testing.assert_array_equal(smp["lls_nhi_samples"], fs["samples"]["lls_nhi_samples"])
+
+
+def fake_results(nq, S, md, seed):
+    rng = np.random.default_rng(seed)
+    if md:
+        out = Batch.empty_results_multi(nq, md, S)
+    else:
+        out = Batch.empty_results(nq, S)
+    for k, v in out.items():
+        if v.dtype == np.float64:
+            v[...] = rng.normal(size=v.shape)
+        elif v.dtype == np.uint32:
+            v[...] = rng.integers(1, S + 1, size=v.shape)
+    mp = rng.uniform(size=out["model_posteriors"].shape)
+    out["model_posteriors"][...] = mp / mp.sum(axis=1, keepdims=True)
+    return out
+
+
+@pytest.mark.parametrize("md", [0, 3])
+def test_chunks_recombine_to_the_whole_run(tmp_path, md):
+    """Three chunk files (5 + 1 + 6 quasars) -> one file equal to the run saved whole."""
+    S, n_all = 16, 20
+    sizes = [5, 1, 6]
+    sel = np.array([0, 2, 3, 4, 6, 7, 9, 10, 12, 13, 15, 19])
+    parts = [fake_results(n, S, md, 10 + i) for i, n in enumerate(sizes)]
+    save = io.save_processed_qsos_multi if md else io.save_processed_qsos
+    paths, lo = [], 0
+    for part, n in zip(parts, sizes):
+        mask = np.zeros(n_all, dtype=bool)
+        mask[sel[lo:lo + n]] = True
+        paths.append(io.chunk_filename(str(tmp_path), "dr12q", lo, lo + n, multi=bool(md)))
+        extra = dict(k=20, num_dla_samples=S) if md else {}
+        save(paths[-1], dict(part, **extra), test_ind=mask, test_set_name="dr12q", release="dr12q")
+        lo += n
+    assert paths == sorted(paths)  # sorting the names orders the chunks
+    assert paths[0].endswith(("processed_qsos_multi_meanfluxdr12q_000000-000005.mat" if md
+                              else "processed_qsos_dr12q_000000-000005.mat"))
+    out = str(tmp_path / "combined.mat")
+    io.combine_processed_chunks(paths, out)
+    whole = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+    back = io.load_processed_qsos(out)
+    for k, v in whole.items():
+        if k in ("status",):
+            continue
+        np.testing.assert_array_equal(np.asarray(back[k]).reshape(v.shape), v, err_msg=k)
+    mask = np.zeros(n_all, dtype=bool)
+    mask[sel] = True
+    np.testing.assert_array_equal(np.asarray(back["test_ind"]).reshape(-1).astype(bool), mask)
+    assert back["test_set_name"] == "dr12q"
+    with hdf5.File(out) as f:  # MATLAB's conventions survive: class attributes, reversed dimensions
+        assert f["p_dlas"].attrs["MATLAB_class"] == "double" and f["p_dlas"].shape == (1, 12)
+        assert f["test_ind"].attrs["MATLAB_class"] == "logical"
+        if md:
+            assert f["sample_log_likelihoods_dla"].shape == (md, S, 12)
+            assert f["base_sample_inds"].attrs["MATLAB_class"] == "uint32"
+
+
+def test_batch_size_defaults():
+    per_q = record_bytes_per_quasar(1500, 20)
+    assert 2.8e6 < per_q < 3.4e6  # 2.9 MB of step records + the interpolated rows
+    assert default_batch_size(2048, 1500, 20, 10000, 3) == 256
+    assert default_batch_size(100, 1500, 20, 10000, 3) == 100 or default_batch_size(100, 1500, 20, 10000, 3) == 128
+    assert default_batch_size(10 ** 6, 1500, 20, 10000, 3) == 4096
+    # memory-bound case: k = 40 records are 29 KB per step
+    assert default_batch_size(10 ** 6, 1500, 40, 10000, 3, budget_bytes=8 * 2 ** 30) < 300
