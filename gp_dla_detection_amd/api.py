@@ -478,10 +478,14 @@ def run_pipeline(ctx: "Context", num_blocks: int, inputs, process, download, slo
         nxt = up_pool.submit(upload, 0)
         for i in range(num_blocks):
             batch = nxt.result()
-            if i + 1 < num_blocks:
+            # upload(i + 1) waits for done[i + 1 - slots]: with one slot that is THIS block's
+            # download, which does not exist before the sweep is launched
+            if slots > 1 and i + 1 < num_blocks:
                 nxt = up_pool.submit(upload, i + 1)
             process(i, batch)
             done[i] = down_pool.submit(download, i, batch)
+            if slots == 1 and i + 1 < num_blocks:
+                nxt = up_pool.submit(upload, i + 1)
         for f in done:
             f.result()
     finally:

@@ -3,8 +3,9 @@
 Every file the inference path consumes or produces is a MATLAB ``-v7.3`` file, i.e. HDF5 behind a
 512-byte MATLAB header (process_qsos.m:250, learn_qso_model.m:123, preload_qsos.m:79,
 generate_dla_samples.m:63), and the downstream consumer opens the output with ``h5py.File``
-(CDDF_analysis/qso_loader.py:84-112, calc_cddf.py:104).  ``h5py`` / libhdf5 are in neither the
-build image nor the GPU box, so this module implements the on-disk format directly, following the
+(CDDF_analysis/qso_loader.py:84-112, calc_cddf.py:104).  The interpreter this package runs under
+(here and on the GPU box) has neither ``h5py`` nor a libhdf5 binding, so this module implements
+the on-disk format directly, following the
 "HDF5 File Format Specification Version 2.0" (superblock 0/1 and 2/3, version-1 and version-2
 object headers, symbol-table groups and compact link-message groups, version-1 B-trees, local
 heaps, contiguous / compact / chunked layouts, the deflate, shuffle and fletcher32 filters,
@@ -21,8 +22,12 @@ by every libhdf5 -- with contiguous or chunked+deflate datasets and object refer
 
 The reader is validated against a file written by MATLAB itself (SciPy ships one,
 ``scipy/io/matlab/tests/data/testhdf5_7.4_GLNX86.mat``) and against this module's writer; the
-writer against the reader and against byte-level checks of the structures it emits
-(tests/test_hdf5.py).  No libhdf5 was available to cross-read: self-validated.
+writer against the reader, against byte-level checks of the structures it emits
+(tests/test_hdf5.py) and against libhdf5 itself: the build image carries libhdf5 1.10.6 with its
+command-line tools and h5py 3.3.0 in a separate conda interpreter (round 2 overlooked both).
+``h5dump`` / ``h5ls`` read this writer's files bit-exactly (tests/test_consumers.py), and the
+reference's own downstream code -- ``mat_combine``, ``QSOLoader``, ``DLACatalogue``, through h5py
+-- opens them (tests/golden/make_consumer_fixtures.py).
 """
 from __future__ import annotations
 

@@ -9,7 +9,8 @@ behind a 512-byte MATLAB header: ``learned_qso_model_*.mat`` (learn_qso_model.m:
 ``f['model_posteriors'][()].T``, ``f['test_ind'][0, :]`` (qso_loader.py:84-112, calc_cddf.py:104).
 
 * ``-v7.3`` files are read and written with the package's own minimal HDF5 implementation
-  (:mod:`.hdf5`): neither h5py nor libhdf5 exists in the build image or on the GPU box.  MATLAB's
+  (:mod:`.hdf5`): the interpreter this package runs under has no h5py (libhdf5 and h5py exist in
+  the build image's conda environment and are used to cross-validate it, tests/test_consumers.py).  MATLAB's
   conventions are applied on top of it here: arrays are stored with their dimensions reversed
   (column-major data in a row-major container), logicals as uint8 and chars as uint16 with the
   ``MATLAB_class`` / ``MATLAB_int_decode`` attributes, cell arrays as object references into the
@@ -373,9 +374,13 @@ def save_processed_qsos(path: str, results: dict, test_ind=None, **run_metadata)
                 _streamed_table(w, k, v)
             else:
                 w.put(k, v)
-        for k in ("MAP_inds", "MAP_z_dlas", "MAP_log_nhis"):  # generate_ascii_catalog.m:73-80 (extra)
+        # The MAP sample of generate_ascii_catalog.m:73-80, which the evidence kernel finds anyway: an
+        # extra, stored as single_MAP_*.  NOT under the multi-DLA names: QSOLoader takes a file with a
+        # 'MAP_log_nhis' key for a multi-DLA file and indexes it [nq, model, slot] (qso_loader.py:106-109,
+        # 160-162) -- found by running the reference's loader on these files.
+        for k in ("MAP_inds", "MAP_z_dlas", "MAP_log_nhis"):
             if k in results and np.ndim(results[k]) == 1:
-                w.put(k, np.asarray(results[k], dtype=np.float64))
+                w.put("single_" + k, np.asarray(results[k], dtype=np.float64))
     finally:
         w.close()
 
@@ -412,6 +417,8 @@ def load_processed_qsos(path: str) -> dict:
                                                         + ("test_ind", "MAP_inds"))
     out = {}
     for k, v in m.items():
+        if k.startswith("single_MAP_"):  # save_processed_qsos: the single-DLA MAP extras
+            k = k[len("single_"):]
         if isinstance(v, np.ndarray):
             if v.ndim == 2 and 1 in v.shape and k not in ("model_posteriors",):
                 v = v.reshape(-1)

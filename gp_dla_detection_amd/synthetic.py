@@ -196,7 +196,8 @@ def write_file_set(directory: str, num_quasars: int = 24, num_samples: int = 256
     (``-v7.3``, column vectors, cell arrays, logical masks): ``catalog.mat`` (build_catalogs.m:86-91:
     the plain per-quasar columns), ``preloaded_qsos.mat`` (preload_qsos.m:64-79),
     ``learned_qso_model_synthetic.mat`` (learn_qso_model.m:113-123), ``dla_samples.mat``
-    (generate_dla_samples.m:59-63 + set_lls_parameters.m:59-63), ``snrs_qsos.mat``, the training
+    (generate_dla_samples.m:59-63 + set_lls_parameters.m:59-63), ``snrs_qsos.mat`` (one entry per
+    searched quasar), the training
     release's ``prior_catalog.npz`` and the two text catalogues ``QSOLoader`` opens
     (qso_loader.py:410-424: ``dla_catalog`` = thing_id, z_dla, log_nhi; ``los_catalog`` = thing_id).
     Every ``skip_every``-th quasar has ``filter_flags != 0`` (outside ``test_ind``); quasar
@@ -235,13 +236,17 @@ def write_file_set(directory: str, num_quasars: int = 24, num_samples: int = 256
         cells[key] = [np.asarray(s[src]).astype(bool if src == "pixel_mask" else np.float64).reshape(-1, 1)
                       for s in spectra]
     io.savemat73(paths["preloaded"], cells, compress=True)
-    io.savemat73(paths["learned"], {k_: (col(v) if np.ndim(v) == 1 else v) for k_, v in model.items()},
-                 compress=True)
+    # learn_qso_model.m: rest_wavelengths, mu and log_omega are ROW vectors (read back as
+    # f['mu'][:, 0], qso_loader.py:211-217), M is [G x k]
+    io.savemat73(paths["learned"], {k_: (np.asarray(v).reshape(1, -1) if np.ndim(v) == 1 else v)
+                                    for k_, v in model.items()}, compress=True)
     io.savemat73(paths["samples"], {k_: v.reshape(1, -1) for k_, v in samples.items()})
-    io.savemat73(paths["snrs"], dict(snrs=col(cat["snrs"])))
+    test_ind = filter_flags == 0
+    # snrs_qsos_*.mat is written for the SEARCHED quasars (calc_cddf.compute_all_snrs runs over the
+    # test set; qso_loader.py:111, :169 and calc_cddf.py:131 index it without test_ind)
+    io.savemat73(paths["snrs"], dict(snrs=col(cat["snrs"][test_ind])))
     prior = make_prior_catalog()
     np.savez(paths["prior"], **prior)
-    test_ind = filter_flags == 0
     # a "concordance" catalogue naming the injected absorbers of some searched quasars
     with open(paths["dla_catalog"], "w") as f:
         for i, s in enumerate(spectra):

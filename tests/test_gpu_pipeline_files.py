@@ -23,7 +23,7 @@ def files(tmp_path_factory):
     all_spectra = [synthetic.make_spectrum(900 + i, 260 + 31 * i, model, mask_fraction=0.05) for i in range(9)]
     test_ind = np.array([1, 0, 1, 1, 0, 1, 1, 0, 1], dtype=bool)
     io.savemat73(str(d / "learned_qso_model_dr9q_minus_concordance.mat"),
-                 {k: (np.asarray(v).reshape(-1, 1) if np.ndim(v) == 1 else v) for k, v in model.items()},
+                 {k: (np.asarray(v).reshape(1, -1) if np.ndim(v) == 1 else v) for k, v in model.items()},  # row vectors
                  compress=True)                                        # learn_qso_model.m:113-123
     io.savemat73(str(d / "dla_samples.mat"), {k: v.reshape(1, -1) for k, v in samples.items()})  # generate_dla_samples.m:59-63
     cells = {}

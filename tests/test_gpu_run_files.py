@@ -102,3 +102,35 @@ def test_file_to_file_run_equals_the_unsharded_run(fileset, tmp_path, world, mul
     assert skipped.size == 1 and sel[skipped[0]] == 7
     summary = io.loadmat73(str(tmp_path / (stem + "summary.mat")))
     np.testing.assert_array_equal(summary["p_dlas"].reshape(-1), ref["p_dlas"])
+
+
+def test_committed_consumer_chunks_are_reproduced(tmp_path):
+    """The chunk files under tests/golden/consumer/ -- the ones the reference's mat_combine, QSOLoader
+    and DLACatalogue were run on (tests/test_consumers.py) -- are what a world-2 run on this GPU
+    writes: same quasars per chunk, values within the parity tolerance (they were produced by an
+    earlier build of the kernels)."""
+    cons = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consumer")
+    fs = synthetic.write_file_set(str(tmp_path / "in"), num_quasars=40, num_samples=24, empty_quasar=None)
+    in_dir = os.path.dirname(fs["paths"]["catalog"])
+    for multi in (False, True):
+        out = tmp_path / ("multi" if multi else "single")
+        out.mkdir()
+        run_world(2, multi, in_dir, out, 4)
+        stem = "processed_qsos_multi_meanfluxsynth_" if multi else "processed_qsos_synth_"
+        new = sorted(glob.glob(str(out / (stem + "[0-9]*.mat"))))
+        old = sorted(glob.glob(os.path.join(cons, stem + "[0-9]*.mat")))
+        assert [os.path.basename(p) for p in new] == [os.path.basename(p) for p in old] and len(old) == 2
+        for a, b in zip(new, old):
+            pa, pb = io.load_processed_qsos(a), io.load_processed_qsos(b)
+            assert sorted(pa) == sorted(pb)
+            for key, vb in pb.items():
+                va = pa[key]
+                if isinstance(vb, str):
+                    assert va == vb
+                elif key == "base_sample_inds":
+                    assert np.mean(np.asarray(va) == np.asarray(vb)) > 0.999
+                elif "sample_log_likelihoods" in key or key.startswith(("log_likelihoods", "log_posteriors")):
+                    np.testing.assert_allclose(va, vb, rtol=0, atol=1e-8, err_msg=key)
+                else:
+                    np.testing.assert_allclose(np.asarray(va, dtype=np.float64), np.asarray(vb, dtype=np.float64),
+                                               rtol=1e-9, atol=1e-9, err_msg=key)
