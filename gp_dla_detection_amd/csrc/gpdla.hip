@@ -17,6 +17,7 @@
 #include "../../include/gpdla.h"
 #include "../../include/gpdla_lyman_series.h"
 #include "multi_kernels.hpp"
+#include "sweep_slim_kernel.hpp"
 #include "sweep_split_kernel.hpp"
 #include "training_kernels.hpp"
 #include "training_mfma_kernels.hpp"
@@ -554,7 +555,7 @@ int batch_fill(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, int md
   chk(reserve(&b->d_pix, &b->cap.pix, (size_t)rows));
   chk(reserve(&b->d_Mi, &b->cap.Mi, (size_t)rows * b->k));
   chk(reserve(&b->d_lam, &b->cap.lam, (size_t)lam));
-  chk(reserve(&b->d_records, &b->cap.records, (size_t)(rows / 4 + kRecordPoolPad) * record_doubles(b->ntiles, 0)));
+  // (the step records are sized by the record class the sweep will use: reserved by launch_prepare)
   if (!md) {
     chk(reserve(&b->d_sample_ll, &b->cap.sample_ll, (size_t)nq * b->S));
     chk(reserve(&b->d_ll_no, &b->cap.ll_no, (size_t)nq));
@@ -639,6 +640,24 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   return GPDLA_OK;
 }
 
+// k_sweep_slim: k <= 20, three lines, fp64, slim records
+int launch_sweep_slim(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
+  const size_t lds = (size_t)kSlimLdsDoubles * sizeof(double);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_slim),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.blocks_per_quasar = (int32_t)((b->S + 1 + kSweepWaves * kSamplesPerWave - 1) / (kSweepWaves * kSamplesPerWave));
+  const int64_t nblocks = 8 * ((b->nq + 7) / 8) * (int64_t)args.blocks_per_quasar;
+  if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "batch too large for one launch");
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL(k_sweep_slim, dim3((unsigned)nblocks), dim3(kSweepWaves * 64), lds, c->stream, args);
+  HIP_TRY(hipGetLastError());
+  if (c->timing) {
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->have_timing = true;
+  }
+  return GPDLA_OK;
+}
+
 // k_sweep_split: 20 < k <= 40 in fp64 (shared Voigt/weight pipeline across the four tile-split waves)
 template <int LINES>
 int launch_sweep_split(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
@@ -670,9 +689,15 @@ extern "C" {
 
 namespace {
 
-// k_prepare + k_build_records for a batch (multi: the mean-flux / Lyman-series variant)
-int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi, bool f32_tiles = false) {
+// k_prepare + k_build_records for a batch (multi: the mean-flux / Lyman-series variant).
+// slim: the 896-byte step records of k_sweep_slim instead of the pre-expanded MFMA tiles.
+int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi, bool f32_tiles = false, bool slim = false) {
   hipStream_t st = c->stream;
+  {
+    const size_t per_step = slim ? (size_t)kSlimRec : (size_t)record_doubles(b->ntiles, 0);
+    int rc = reserve(&b->d_records, &b->cap.records, (size_t)(b->pool_rows / 4 + kRecordPoolPad) * per_step);
+    if (rc) return rc;
+  }
   Config cfg;
   cfg.min_lambda = c->cfg.min_lambda;
   cfg.max_lambda = c->cfg.max_lambda;
@@ -711,9 +736,12 @@ int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi, bool f32_tiles 
   ba.k = b->k;
   ba.tiles_w = b->tiles_w;
   ba.ntiles = b->ntiles;
-  ba.blocks_per_quasar = 16;
+  ba.blocks_per_quasar = slim ? 4 : 16;
   ba.f32_tiles = f32_tiles ? 1 : 0;
-  hipLaunchKernelGGL(k_build_records, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
+  if (slim)
+    hipLaunchKernelGGL(k_build_slim_records, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
+  else
+    hipLaunchKernelGGL(k_build_records, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
   HIP_TRY(hipGetLastError());
   return GPDLA_OK;
 }
@@ -729,9 +757,13 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   if (b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA batch: use gpdla_batch_process_multi");
   HIP_TRY(hipSetDevice(c->device_id));
   hipStream_t st = c->stream;
-  int rc = launch_prepare(c, b, false, c->cfg.contraction_precision == 1);
-  if (rc) return rc;
   const int num_lines = c->cfg.num_lines;
+  // k <= 20, three lines, fp64: slim step records, vech(m m') formed inside the sweep (k_sweep_slim).
+  // GPDLA_EXPANDED_RECORDS=1 (diagnostic): the pre-expanded records of k_sweep, for A/B timing.
+  static const bool expanded = std::getenv("GPDLA_EXPANDED_RECORDS") != nullptr;
+  const bool slim = b->k <= 20 && num_lines == 3 && c->cfg.contraction_precision == 0 && !expanded;
+  int rc = launch_prepare(c, b, false, c->cfg.contraction_precision == 1, slim);
+  if (rc) return rc;
 
   // NaN pre-fill, as process_qsos.m:74-82 does for quasars that are skipped
   HIP_TRY(hipMemsetAsync(b->d_sample_ll, 0xFF, (size_t)b->nq * b->S * sizeof(double), st));
@@ -757,7 +789,9 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.blocks_per_quasar = 0;  // set by launch_sweep
   const bool three = num_lines == 3;
   const bool f32 = c->cfg.contraction_precision == 1;
-  if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
+  if (slim) {
+    rc = launch_sweep_slim(c, b, sa);
+  } else if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
     if (!f32) rc = three ? launch_sweep<double, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
     else rc = three ? launch_sweep<float, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
   } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles
