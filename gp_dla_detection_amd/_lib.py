@@ -66,7 +66,7 @@ class Config(C.Structure):
                 ("min_z_separation", C.c_double), ("prev_tau_0", C.c_double),
                 ("prev_beta", C.c_double), ("rng_seed", C.c_uint64),
                 ("first_quasar_index", C.c_int64), ("contraction_precision", C.c_int32),
-                ("multi_profile_bytes", C.c_int64)]
+                ("multi_profile_bytes", C.c_int64), ("record_pool_bytes", C.c_int64)]
 
 
 class Results(C.Structure):

@@ -42,7 +42,8 @@ def _config(params: Parameters) -> _lib.Config:
                  "max_z_cut", "min_z_cut", "width", "num_lines"):
         setattr(cfg, name, getattr(params, name))
     for name in ("max_dlas", "num_forest_lines", "min_z_separation", "prev_tau_0", "prev_beta",
-                 "rng_seed", "first_quasar_index", "contraction_precision", "multi_profile_bytes"):
+                 "rng_seed", "first_quasar_index", "contraction_precision", "multi_profile_bytes",
+                 "record_pool_bytes"):
         if hasattr(params, name):
             setattr(cfg, name, getattr(params, name))
     return cfg
@@ -427,21 +428,32 @@ class Batch:
 # the script surface
 # ----------------------------------------------------------------------------------------------
 
-def record_bytes_per_quasar(num_pixels: int, k: int) -> int:
-    """HBM a quasar of ``num_pixels`` stored pixels occupies in a resident batch: its step records
-    (one per 4 pixels; record_doubles() in csrc/sweep_kernels.hpp: 14 tiles x 64 + 64 doubles for
-    k <= 20, 56 x 64 + 128 for k <= 40) plus the interpolated rows (k + 4 doubles per pixel)."""
-    per_step = (14 * 64 + 64) if k <= 20 else (56 * 64 + 128)
-    return int((num_pixels / 4 + 2) * per_step * 8 + (num_pixels + 8) * (k + 6) * 8)
+def record_bytes_per_quasar(num_pixels: int, k: int, slim: bool = True) -> int:
+    """Bytes of K-step records (one per 4 pixels) a quasar of ``num_pixels`` stored pixels needs in
+    the record pool: 896 B per step for k <= 20 (k_sweep_slim: the M rows, pixel rows and
+    wavelengths; ``slim=False``: the 7680-byte pre-expanded records of k_sweep, used for other line
+    counts and the fp32 study), 29 696 B for 20 < k <= 40.  The pool is bounded by
+    ``Parameters.record_pool_bytes`` whatever the batch size (the library sweeps group by group)."""
+    per_step = (896 if slim else 7680) if k <= 20 else 29696
+    return int((num_pixels / 4 + 2) * per_step)
+
+
+def resident_bytes_per_quasar(num_pixels: int, k: int, num_samples: int, multi_models: int = 0) -> int:
+    """HBM a quasar occupies in a resident batch apart from the record pool: its spectrum, the
+    interpolated rows (k + 4 doubles per pixel), the padded wavelengths and its result tables."""
+    rows = (num_pixels + 8) * (k + 4 + 1 + 3.2) * 8
+    return int(rows + 8 * num_samples * max(1, 2 * multi_models))
 
 
 def default_batch_size(num_quasars: int, longest: int, k: int, num_samples: int, slots: int,
                        budget_bytes: float = 96 * 2**30, multi_models: int = 0) -> int:
-    """Quasars per batch of the host pipeline: small enough that ``slots`` batches (records + result
-    tables) fit ``budget_bytes`` of HBM and that a run has ~8 batches to overlap (the first upload
-    and the last download are the only copies not hidden behind a sweep), at least 128 so that a
-    launch fills the 256 CUs many times over."""
-    per_q = record_bytes_per_quasar(longest, k) + 8 * num_samples * max(1, 2 * multi_models)
+    """Quasars per batch of the host pipeline: small enough that ``slots`` batches fit
+    ``budget_bytes`` of HBM next to the record pool and that a run has ~8 batches to overlap (the
+    first upload and the last download are the only copies not hidden behind a sweep), at least
+    128 so that a launch fills the 256 CUs many times over."""
+    per_q = resident_bytes_per_quasar(longest, k, num_samples, multi_models)
+    if multi_models:  # the multi-DLA sweeps build all records of a batch up front
+        per_q += record_bytes_per_quasar(longest, k, slim=False)
     cap = max(1, int(budget_bytes / slots / per_q))
     want = max(128, -(-num_quasars // 8))
     return max(1, min(cap, want, 4096))

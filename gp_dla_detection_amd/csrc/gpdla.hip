@@ -184,8 +184,17 @@ struct gpdla_batch {
   // (hipFree waits for the whole device) in the steady state
   struct {
     size_t offsets = 0, wl = 0, flux = 0, nv = 0, z = 0, mask = 0, lp_no = 0, lp_dla = 0, meta = 0, order = 0,
-           pix = 0, Mi = 0, lam = 0, records = 0, sample_ll = 0, ll_no = 0, summary = 0;
+           pix = 0, Mi = 0, lam = 0, records = 0, sample_ll = 0, ll_no = 0, summary = 0, rec_off = 0;
   } cap;
+  // Record plan (plan_records): the K-step records of the batch's quasars live in ONE pool of at most
+  // cfg.record_pool_bytes; quasars are taken in dealing order (h_order: decreasing length) and cut
+  // into groups whose records fit, each group built and swept in turn.
+  std::vector<int32_t> h_order;                            // host copy of d_order
+  std::vector<int64_t> h_recs;                             // records a quasar occupies (K-steps + 1), by quasar
+  std::vector<int64_t> h_rec_off;                          // planned pool offset (in records), by quasar
+  std::vector<std::pair<int64_t, int64_t>> groups;         // [g0, g1) ranges of h_order
+  int64_t *d_rec_off = nullptr;
+  int64_t plan_per_step = 0, plan_budget = -1, plan_pool_records = 0;  // what the current plan was made for
   int64_t nq = 0, S = 0, total_pix = 0;
   int64_t *d_offsets = nullptr;
   double *d_wl = nullptr, *d_flux = nullptr, *d_nv = nullptr, *d_z = nullptr;
@@ -250,6 +259,7 @@ void gpdla_default_config(gpdla_config *cfg) {
   cfg->first_quasar_index = 0;
   cfg->contraction_precision = 0;
   cfg->multi_profile_bytes = 0;
+  cfg->record_pool_bytes = 0;
 }
 
 /* ------------------------------ context ------------------------------ */
@@ -448,6 +458,7 @@ void gpdla_batch_destroy(gpdla_batch *b) {
   dev_free(b->d_sample_ll);
   dev_free(b->d_ll_no);
   dev_free(b->d_summary);
+  dev_free(b->d_rec_off);
   delete b->mb;
   delete b;
 }
@@ -521,6 +532,9 @@ int batch_fill(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, int md
     b->max_pix = std::max(b->max_pix, npix);
   }
   b->pool_rows = rows;
+  b->h_recs.resize((size_t)nq);
+  for (int64_t q = 0; q < nq; ++q) b->h_recs[q] = (off[q + 1] - off[q] + 3) / 4 + 1;
+  b->plan_budget = -1;  // the record plan is remade by the next process call
   if (b->md != md) {  // (reload with a different kind of batch)
     delete b->mb;
     b->mb = nullptr;
@@ -552,6 +566,7 @@ int batch_fill(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, int md
     return off[x + 1] - off[x] > off[y + 1] - off[y];
   });
   chk(reserve_copy(&b->d_order, &b->cap.order, order.data(), (size_t)nq, st));
+  b->h_order = order;
   chk(reserve(&b->d_pix, &b->cap.pix, (size_t)rows));
   chk(reserve(&b->d_Mi, &b->cap.Mi, (size_t)rows * b->k));
   chk(reserve(&b->d_lam, &b->cap.lam, (size_t)lam));
@@ -689,15 +704,44 @@ extern "C" {
 
 namespace {
 
-// k_prepare + k_build_records for a batch (multi: the mean-flux / Lyman-series variant).
-// slim: the 896-byte step records of k_sweep_slim instead of the pre-expanded MFMA tiles.
-int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi, bool f32_tiles = false, bool slim = false) {
-  hipStream_t st = c->stream;
-  {
-    const size_t per_step = slim ? (size_t)kSlimRec : (size_t)record_doubles(b->ntiles, 0);
-    int rc = reserve(&b->d_records, &b->cap.records, (size_t)(b->pool_rows / 4 + kRecordPoolPad) * per_step);
+// Plan the record pool of a batch for records of `per_step` doubles: offsets per quasar, groups of
+// quasars (in dealing order) whose records fit the pool budget, the pool itself.  Remade only when
+// the record class, the budget or the batch's contents changed.
+int plan_records(gpdla_context *c, gpdla_batch *b, int64_t per_step, bool single_group) {
+  const int64_t budget_bytes = c->cfg.record_pool_bytes > 0 ? c->cfg.record_pool_bytes : (int64_t)16 << 30;
+  const int64_t budget = single_group ? INT64_MAX : std::max<int64_t>(1, budget_bytes / (per_step * 8));
+  if (b->plan_per_step != per_step || b->plan_budget != budget) {
+    const int64_t nq = b->nq;
+    b->h_rec_off.assign((size_t)nq, 0);
+    b->groups.clear();
+    int64_t cur = 0, g0 = 0, most = 0;
+    for (int64_t i = 0; i < nq; ++i) {
+      const int64_t q = b->h_order[(size_t)i], n = b->h_recs[(size_t)q];
+      if (cur > 0 && cur + n > budget) {
+        b->groups.emplace_back(g0, i);
+        most = std::max(most, cur);
+        g0 = i;
+        cur = 0;
+      }
+      b->h_rec_off[(size_t)q] = cur;
+      cur += n;
+    }
+    b->groups.emplace_back(g0, nq);
+    most = std::max(most, cur);
+    b->plan_pool_records = most + kRecordPoolPad;
+    b->plan_per_step = per_step;
+    b->plan_budget = budget;
+    int rc = reserve(&b->d_rec_off, &b->cap.rec_off, (size_t)nq);
     if (rc) return rc;
+    // (h_rec_off lives as long as the batch: the copy may complete after this call returns)
+    HIP_TRY(hipMemcpyAsync(b->d_rec_off, b->h_rec_off.data(), (size_t)nq * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   }
+  return reserve(&b->d_records, &b->cap.records, (size_t)b->plan_pool_records * (size_t)per_step);
+}
+
+// k_prepare for a batch (multi: the mean-flux / Lyman-series variant)
+int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi) {
+  hipStream_t st = c->stream;
   Config cfg;
   cfg.min_lambda = c->cfg.min_lambda;
   cfg.max_lambda = c->cfg.max_lambda;
@@ -721,12 +765,19 @@ int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi, bool f32_tiles 
   pa.pix = b->d_pix;
   pa.Mi = b->d_Mi;
   pa.lam_pad = b->d_lam;
+  pa.rec_off = b->d_rec_off;
   pa.multi = multi ? 1 : 0;
   pa.num_forest_lines = c->cfg.num_forest_lines;
   pa.prev_tau_0 = c->cfg.prev_tau_0;
   pa.prev_beta = c->cfg.prev_beta;
   hipLaunchKernelGGL(k_prepare, dim3((unsigned)b->nq), dim3(256), 0, st, pa);
   HIP_TRY(hipGetLastError());
+  return GPDLA_OK;
+}
+
+// The K-step records of the quasars h_order[g0 .. g1) into the pool.  slim: the 896-byte records of
+// k_sweep_slim instead of the pre-expanded MFMA tiles.
+int launch_build_records(gpdla_context *c, gpdla_batch *b, int64_t g0, int64_t g1, bool f32_tiles, bool slim) {
   BuildRecordsArgs ba;
   ba.meta = b->d_meta;
   ba.pix = b->d_pix;
@@ -738,10 +789,12 @@ int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi, bool f32_tiles 
   ba.ntiles = b->ntiles;
   ba.blocks_per_quasar = slim ? 4 : 16;
   ba.f32_tiles = f32_tiles ? 1 : 0;
+  ba.order = b->d_order + g0;
+  const unsigned grid = (unsigned)((g1 - g0) * ba.blocks_per_quasar);
   if (slim)
-    hipLaunchKernelGGL(k_build_slim_records, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
+    hipLaunchKernelGGL(k_build_slim_records, dim3(grid), dim3(256), 0, c->stream, ba);
   else
-    hipLaunchKernelGGL(k_build_records, dim3((unsigned)(b->nq * ba.blocks_per_quasar)), dim3(256), 0, st, ba);
+    hipLaunchKernelGGL(k_build_records, dim3(grid), dim3(256), 0, c->stream, ba);
   HIP_TRY(hipGetLastError());
   return GPDLA_OK;
 }
@@ -761,9 +814,12 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   // k <= 20, three lines, fp64: slim step records, vech(m m') formed inside the sweep (k_sweep_slim).
   // GPDLA_EXPANDED_RECORDS=1 (diagnostic): the pre-expanded records of k_sweep, for A/B timing.
   static const bool expanded = std::getenv("GPDLA_EXPANDED_RECORDS") != nullptr;
-  const bool slim = b->k <= 20 && num_lines == 3 && c->cfg.contraction_precision == 0 && !expanded;
-  int rc = launch_prepare(c, b, false, c->cfg.contraction_precision == 1, slim);
+  const bool f32 = c->cfg.contraction_precision == 1;
+  const bool slim = b->k <= 20 && num_lines == 3 && !f32 && !expanded;
+  if (b->k > 40) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d needs %d B tiles (max 56)", b->k, b->ntiles);
+  int rc = plan_records(c, b, slim ? kSlimRec : record_doubles(b->ntiles, 0), false);
   if (rc) return rc;
+  if ((rc = launch_prepare(c, b, false))) return rc;
 
   // NaN pre-fill, as process_qsos.m:74-82 does for quasars that are skipped
   HIP_TRY(hipMemsetAsync(b->d_sample_ll, 0xFF, (size_t)b->nq * b->S * sizeof(double), st));
@@ -776,10 +832,8 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.offset_samples = c->d_offset;
   sa.nhi_samples = c->d_nhi;
   sa.perm = c->d_perm;
-  sa.order = b->d_order;
   sa.pix = b->d_pix;
   sa.S = b->S;
-  sa.nq = b->nq;
   sa.k = b->k;
   sa.tiles_w = b->tiles_w;
   sa.ntiles = b->ntiles;
@@ -788,14 +842,21 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   sa.ll_no_dla = b->d_ll_no;
   sa.blocks_per_quasar = 0;  // set by launch_sweep
   const bool three = num_lines == 3;
-  const bool f32 = c->cfg.contraction_precision == 1;
-  if (slim) {
-    rc = launch_sweep_slim(c, b, sa);
-  } else if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
-    if (!f32) rc = three ? launch_sweep<double, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
-    else rc = three ? launch_sweep<float, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
-  } else if (b->k <= 40) {  // 52 w-tiles (<= 820) + 4 u-tiles
-    if (!f32) {  // fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
+  // the timed region of gpdla_context_last_sweep_ms spans the sweeps of all groups (one group unless
+  // the records exceed cfg.record_pool_bytes)
+  const bool timing = c->timing;
+  if (timing) HIP_TRY(hipEventRecord(c->ev0, st));
+  c->timing = false;
+  for (const auto &g : b->groups) {
+    if ((rc = launch_build_records(c, b, g.first, g.second, f32, slim))) break;
+    sa.order = b->d_order + g.first;
+    sa.nq = g.second - g.first;
+    if (slim) {
+      rc = launch_sweep_slim(c, b, sa);
+    } else if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
+      if (!f32) rc = three ? launch_sweep<double, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
+      else rc = three ? launch_sweep<float, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
+    } else if (!f32) {  // 52 w-tiles (<= 820) + 4 u-tiles; fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
       // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k_sweep form in which every wave of a group repeats
       // the Voigt/weight arithmetic, for A/B timing against k_sweep_split
       static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
@@ -803,13 +864,17 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
         rc = three ? launch_sweep<double, 8, 14, 4, 2, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
       else
         rc = three ? launch_sweep_split<3>(c, b, sa) : launch_sweep_split<0>(c, b, sa);
-    }
-    else       // fp32: 224 accumulator registers fit one wave (4-wave blocks, one wave per SIMD)
+    } else {  // fp32: 224 accumulator registers fit one wave (4-wave blocks, one wave per SIMD)
       rc = three ? launch_sweep<float, 4, 56, 1, 4, 52, 3>(c, b, sa) : launch_sweep<float, 4, 56, 1, 4, 52, 0>(c, b, sa);
-  } else {
-    rc = fail(GPDLA_ERR_UNSUPPORTED, "k = %d needs %d B tiles (max 56)", b->k, b->ntiles);
+    }
+    if (rc) break;
   }
+  c->timing = timing;
   if (rc) return rc;
+  if (timing) {
+    HIP_TRY(hipEventRecord(c->ev1, st));
+    c->have_timing = true;
+  }
 
   EvidenceArgs ea;
   ea.meta = b->d_meta;
@@ -1079,7 +1144,11 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
   if (rc) return rc;
   MultiBuffers &mb = *b->mb;
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, st));
+  // (the multi-DLA sweeps walk the batch in profile-table sub-batches of their own: all records
+  // are built up front, one group)
+  if ((rc = plan_records(c, b, record_doubles(b->ntiles, 0), true))) return rc;
   if ((rc = launch_prepare(c, b, true))) return rc;
+  if ((rc = launch_build_records(c, b, 0, b->nq, false, false))) return rc;
   // NaN pre-fill (multi :110-131); alive != 0; base = 0 (multi :116) or the caller's indices
   HIP_TRY(hipMemsetAsync(mb.sll_dla, 0xFF, nqs * md * S * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(mb.sll_lls, 0xFF, nqs * S * sizeof(double), st));

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     }
     rows[j] = a.prof + ((ql * 2) * a.S + kk) * a.stride;
   }
-  const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
+  const double *rec_base = a.records + m.rec_off * (int64_t)RD;
   const int nrec = m.steps + 1;
   const int nchunks = (nrec + kChunkSteps - 1) / kChunkSteps;
   static_assert((kChunkSteps * RD) % 128 == 0, "a chunk is a whole number of KiB");

@@ -90,6 +90,8 @@ struct QuasarMeta {
   double max_z_dla;  // :160
   int64_t pix_off;   // first row of this quasar in the pixel pools (multiple of 4)
   int64_t lam_off;   // first entry in the padded-wavelength pool
+  int64_t rec_off;   // first K-step record in the record pool (records of a group of quasars share the
+                     // pool: PrepareArgs::rec_off; without groups it is pix_off / 4)
   // 0, or -inf when a kept pixel has noise variance +inf (a zero inverse variance the mask missed):
   // log_mvnpdf_low_rank.m:30 then sums log(inf) into the log-determinant and every log-likelihood of
   // the quasar is -inf.  The sweeps treat that pixel as neutral and add this to each result, so the
@@ -128,6 +130,7 @@ struct PrepareArgs {
   PixelRow *pix;           // pool
   double *Mi;              // pool [row][k] interpolated (and zeroed for masked rows) M
   double *lam_pad;         // pool
+  const int64_t *rec_off;  // [nq] record-pool offsets planned by the host (gpdla.hip plan_records)
   // multi-DLA driver only (process_qsos_multiple_dlas_meanflux.m:245-293): Lyman-series noise
   // scaling and mean-flux suppression of mu, M, omega2
   int32_t multi;
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(256) void k_prepare(PrepareArgs a) {
     m.n_kept = n_kept;
     m.steps = steps;
     m.status = (n_kept > 0) ? ((nv_flags & 2) ? 3 : 0) : 1;
+    m.rec_off = a.rec_off[q];
     m.ll_bias = (nv_flags & 1) ? -INFINITY : 0.0;
     if (n_kept > 0) {
       // set_parameters.m:65-73 on the kept-pixel wavelengths (process_qsos.m:159-160)
@@ -340,6 +344,7 @@ struct BuildRecordsArgs {
   int32_t k, tiles_w, ntiles;
   int32_t blocks_per_quasar;
   int32_t f32_tiles;      // 1: tiles stored as float (the fp32-contraction study), 0: double
+  const int32_t *order;   // the records of quasars order[0 .. grid / blocks_per_quasar) are built
 };
 
 // Tile classes.  k <= 40: ntiles = 52 w-tiles + 4 u-tiles.  k <= 20 ("compact", ntiles == 14): 13
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
   constexpr int SB = 8;  // steps staged per pair of barriers
   __shared__ double s_rows[SB * 4][GPDLA_MAX_K];
   __shared__ uint8_t s_vi[52 * 16], s_vj[52 * 16];
-  const int q = blockIdx.x / a.blocks_per_quasar;
+  const int q = a.order[blockIdx.x / a.blocks_per_quasar];
   const int bq = blockIdx.x % a.blocks_per_quasar;
   const QuasarMeta m = a.meta[q];
   const int tid = threadIdx.x;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void k_build_records(BuildRecordsArgs a) {
     s_vi[c] = (uint8_t)i;
     s_vj[c] = (uint8_t)j;
   }
-  double *out = a.records + (m.pix_off / 4) * (int64_t)RD;
+  double *out = a.records + m.rec_off * (int64_t)RD;
   const int nrec = m.steps + 1;  // record `steps` is the neutral trailing one
   for (int step0 = bq * SB; step0 < nrec; step0 += a.blocks_per_quasar * SB) {
     const int nst = min(SB, nrec - step0);
@@ -1121,7 +1126,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   // exp(N * total / (sqrt(2 pi) sigma)) with total = -Sum lead_j Re w_j (voigt.c:288-291)
   // (times 64/ln2: the exp below takes its argument pre-scaled, exp_table_begin_scaled)
   const double nscale64 = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;
-  const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
+  const double *rec_base = a.records + m.rec_off * (int64_t)RD;
   const int nchunks = (m.steps + kChunkSteps - 1) / kChunkSteps;
 
   // asynchronous global -> LDS copy of one chunk of records (see glds_chunk)

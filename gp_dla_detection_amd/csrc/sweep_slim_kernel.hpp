@@ -18,7 +18,7 @@
 //     208, 209).  Per tile: one ds_read_b64 (immediate offset 8 n), one v_mul_f64, one ds_write_b64.
 //   * Who does it.  Wave w of the block expands K-step w of the NEXT chunk (8 steps per chunk, 8
 //     waves) into the tile buffer the block will read after the next barrier, spread over K-steps
-//     0..4 of the current chunk: 13 multiplies per wave and chunk, 1.6 per K-step, against 93 VALU
+//     0..6 of the current chunk: 13 multiplies per wave and chunk, 1.6 per K-step, against 93 VALU
 //     instructions a K-step already has.  Its 4 M rows arrive by a private 1-KiB LDS-DMA whose
 //     per-lane source addresses lay each 16-double row down twice (that is what makes (c + n) mod 16
 //     an immediate offset); nobody else reads that landing zone, so it needs no barrier.
@@ -88,12 +88,12 @@ __host__ __device__ constexpr int slim_pos(int tile, int col) {
 // neutral, as k_build_records' trailing one.  A pure gather: 112 doubles per K-step.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_build_slim_records(BuildRecordsArgs a) {
-  const int q = blockIdx.x / a.blocks_per_quasar;
+  const int q = a.order[blockIdx.x / a.blocks_per_quasar];
   const int bq = blockIdx.x % a.blocks_per_quasar;
   const QuasarMeta m = a.meta[q];
   const int k = a.k;
   const int n_pad = m.n_u + 6;
-  double *out = a.records + (m.pix_off / 4) * (int64_t)kSlimRec;
+  double *out = a.records + m.rec_off * (int64_t)kSlimRec;
   const int64_t total = (int64_t)(m.steps + 1) * kSlimRec;
   for (int64_t e = (int64_t)bq * 256 + threadIdx.x; e < total; e += (int64_t)a.blocks_per_quasar * 256) {
     const int step = (int)(e / kSlimRec), r = (int)(e - (int64_t)step * kSlimRec);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
   const double *lam = a.lam_pad + m.lam_off;
   const int n_pad = m.n_u + 6;
   const double nscale64 = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;
-  const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)kSlimRec;
+  const double *rec_base = a.records + m.rec_off * (int64_t)kSlimRec;
   const int nchunks = (m.steps + CH - 1) / CH;
 
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
   const double *a8 = s < 8 ? row : bc + (slim_pair_i(8, s) - 16);
   const double *b8 = s < 8 ? row + 8 : bc + (slim_pair_j(8, s) - 16);
   struct Operands {
-    double mc, o[3], p8;
+    double mc, o[2], p8;
   };
   auto expand_load = [&](int t0, int t1, Operands &x) {
     x.mc = row[0];
@@ -293,15 +293,10 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
   const double tap0 = g_lines.taps[0], tap1 = g_lines.taps[1], tap2 = g_lines.taps[2], tap3 = g_lines.taps[3];
 
   glds_wait();  // this wave's rows of chunk 0 (and its share of the raw chunk) landed
-  for (int t0 = 0; t0 < kSlimTilesW; t0 += 3) {
-    Operands x;
-    const int t1 = min(t0 + 3, kSlimTilesW);
-    x.mc = row[0];
-    for (int t = t0; t < t1; ++t) {
-      x.o[t - t0] = t == 8 ? a8[0] : t == 0 ? x.mc : t < 8 ? row[t] : bc[t - 9];
-      if (t == 8) x.p8 = b8[0];
-      xd0[t * 64] = (t == 8 ? x.p8 : x.mc) * x.o[t - t0];
-    }
+  {
+    const double mc = row[0];
+    for (int t = 0; t < kSlimTilesW; ++t)
+      xd0[t * 64] = (t == 8 ? b8[0] : mc) * (t == 8 ? a8[0] : t == 0 ? mc : t < 8 ? row[t] : bc[t - 9]);
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the landing zone has been read ...
   if (nchunks > 1) issue_private(1);   // ... and may be refilled
@@ -309,11 +304,14 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
   __syncthreads();
 
   // One chunk of 8 K-steps per iteration, from parity c & 1.  While it runs, this wave expands its
-  // K-step of chunk c + 1 into the other parity: 3, 3, 3, 2, 2 tiles in K-steps 0..4 (operands
-  // requested before the MFMA burst, multiplied and stored behind it; unconditionally: after the
-  // last chunk the products of stale rows land in a buffer nobody reads), and in K-step 5 refills
-  // its landing zone for chunk c + 2 -- every read of it has been consumed by a multiply by then,
-  // and the copy lands before the chunk's closing barrier.
+  // K-step of chunk c + 1 into the other parity: two tiles in each of K-steps 0..5, one in K-step 6
+  // (operands requested before the MFMA burst, multiplied and stored behind it; unconditionally:
+  // after the last chunk the products of stale rows land in a buffer nobody reads), and in K-step
+  // 7 refills its landing zone for chunk c + 2 -- every read of it has been consumed by a multiply
+  // by then, and the 1-KiB copy lands during that K-step's burst, before the chunk's closing
+  // barrier.  Measured against the alternatives on one box (tools/ab.sh, ms per launch): this
+  // 149.6; three tiles per K-step over five K-steps 150.1; products stored before the burst 152.0;
+  // without the explicit lgkmcnt(0) at the top of a K-step 153.1; pre-expanded records (k_sweep) 149.5.
   for (int c = 0; c < nchunks; ++c) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // (nothing of ours is in flight: see k_sweep)
     if (c + 1 < nchunks) issue_chunk(c + 1);
@@ -326,8 +324,9 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
 #pragma unroll
     for (int tt = 0; tt < CH; ++tt) {
       const int rn = c * CH + tt;
-      constexpr int kT0[5] = {0, 3, 6, 9, 11}, kT1[5] = {3, 6, 9, 11, 13};
-      if (tt == 5 && c + 2 < nchunks) issue_private(c + 2);
+      constexpr int kXS = 7;  // K-steps that carry expansion work
+      constexpr int kT0[7] = {0, 2, 4, 6, 8, 10, 12}, kT1[7] = {2, 4, 6, 8, 10, 12, 13};
+      if (tt == kXS && c + 2 < nchunks) issue_private(c + 2);
       if (rn < m.steps) {
         const double *tl = tbuf + (size_t)tt * kSlimStepTiles;
         const double *mine = mine0 + (size_t)tt * kSlimRec;
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
           dprod = __builtin_amdgcn_frexp_mant(dprod);
         }
         Operands x;
-        if (tt < 5) expand_load(kT0[tt < 5 ? tt : 0], kT1[tt < 5 ? tt : 0], x);
+        if (tt < kXS) expand_load(kT0[tt < kXS ? tt : 0], kT1[tt < kXS ? tt : 0], x);
         if (tt + 1 < CH) lam_next = mine[kSlimRec + 10];
         __builtin_amdgcn_sched_barrier(0);
         // (4) rank-4 update of [B | v] on the matrix cores
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
           xu[2] = fma(u, u23.x, xu[2]);
           xu[3] = fma(u, u23.y, xu[3]);
         }
-        if (tt < 5) expand_store(xdst, kT0[tt < 5 ? tt : 0], kT1[tt < 5 ? tt : 0], x);
+        if (tt < kXS) expand_store(xdst, kT0[tt < kXS ? tt : 0], kT1[tt < kXS ? tt : 0], x);
       }
     }
     glds_wait();      // the prefetched raw chunk and this wave's next rows have landed ...

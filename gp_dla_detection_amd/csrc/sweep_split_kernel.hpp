@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512) void k_sweep_split(SweepArgs a) {
   const PixelRow *pix = a.pix + m.pix_off;
   const int n_pad = m.n_u + 6;
   const double nscale64 = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;  // (pre-scaled exp, sweep_kernels.hpp)
-  const double *rec_base = a.records + (m.pix_off / 4) * (int64_t)RD;
+  const double *rec_base = a.records + m.rec_off * (int64_t)RD;
   const int nchunks = (m.steps + CH - 1) / CH;
   const int niter = (m.steps + 3) / 4;
   const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;

@@ -35,6 +35,9 @@ class Parameters:
     min_z_cut: float = kms_to_z(3000)      # :69
     # 0: fp64 contraction (parity-grade, default); 1: fp32-matrix-core study variant (BASELINE config 5)
     contraction_precision: int = 0
+    # HBM budget of a batch's per-K-step records; a larger batch is swept group by group through one
+    # pool of this size (results do not depend on it); 0 = 16 GiB
+    record_pool_bytes: int = 0
 
     def min_z_dla(self, wavelengths, z_qso):
         """set_parameters.m:70-73"""

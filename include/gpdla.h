@@ -127,6 +127,12 @@ typedef struct {
   /* multi-DLA driver: bytes of HBM the per-quasar Voigt profile table (2 S rows per quasar) may take
    * at a time; quasars are swept in sub-batches that fit.  0 = default (16 GiB). */
   int64_t multi_profile_bytes;
+  /* single-DLA sweep: bytes of HBM the per-K-step records of a batch may take at a time.  A batch
+   * whose records exceed it is swept in groups of quasars (records built, then swept, group after
+   * group into the same pool), so that the resident size of a batch is its spectra and results, not
+   * its records: 0.9 KB per K-step for k <= 20, but 29 KB for 20 < k <= 40 -- 228 GB for a DR12Q
+   * shard.  Results do not depend on it.  0 = default (16 GiB). */
+  int64_t record_pool_bytes;
 } gpdla_config;
 
 /* Fills a gpdla_config with the reference's defaults (set_parameters.m / set_parameters_multi.m). */

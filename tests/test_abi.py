@@ -66,7 +66,7 @@ int main(void) {
   OFF(gpdla_spectra, pixel_mask); OFF(gpdla_spectra, log_priors_lls);
   OFF(gpdla_config, width); OFF(gpdla_config, max_dlas); OFF(gpdla_config, min_z_separation);
   OFF(gpdla_config, rng_seed); OFF(gpdla_config, contraction_precision);
-  OFF(gpdla_config, multi_profile_bytes);
+  OFF(gpdla_config, multi_profile_bytes); OFF(gpdla_config, record_pool_bytes);
   OFF(gpdla_results, status); OFF(gpdla_results, MAP_log_nhis);
   OFF(gpdla_results_multi, base_sample_inds); OFF(gpdla_results_multi, status);
   gpdla_config cfg;
@@ -74,7 +74,7 @@ int main(void) {
   gpdla_default_config(&cfg);
   if (gpdla_abi_version() != GPDLA_ABI_VERSION) return 2;
   if (cfg.width != 3 || cfg.num_lines != 3 || cfg.max_dlas != 4 || cfg.min_lambda != 911.75) return 3;
-  if (cfg.multi_profile_bytes != 0) return 4;
+  if (cfg.multi_profile_bytes != 0 || cfg.record_pool_bytes != 0) return 4;
   uint32_t ctr[4] = {0, 0, 0, 0}, key[2] = {0, 0}, out[4];
   gpdla_debug_philox4x32_10(ctr, key, out);
   if (out[0] != 0x6627e8d5u) return 5;

@@ -427,6 +427,26 @@ def test_chunked_driver_matches_single_batch(model20):
     np.testing.assert_array_equal(one["sample_log_likelihoods_dla"], default["sample_log_likelihoods_dla"])
 
 
+def test_record_pool_groups_do_not_change_results(model20):
+    """A batch whose K-step records exceed Parameters.record_pool_bytes is swept group by group
+    through one pool (records built, swept, next group): identical results for every record class
+    -- slim (k <= 20, 3 lines), pre-expanded (5 lines; fp32 study), and the k <= 40 tile split."""
+    samples = synthetic.make_samples(48)
+    for k, extra in ((20, {}), (20, dict(num_lines=5)), (20, dict(contraction_precision=1)), (33, {})):
+        model = model20 if k == 20 else synthetic.make_model(k)
+        spectra = [synthetic.make_spectrum(700 + i, n, model, mask_fraction=0.02)
+                   for i, n in enumerate([300, 90, 410, 150, 222, 505, 64])]
+        lp = flat_priors(len(spectra))
+        one = gp.process_qsos(model, samples, spectra, log_priors=lp, params=gp.Parameters(**extra),
+                              max_quasars_per_batch=len(spectra))
+        # 505 pixels = 128 K-step records; a pool of 150 records holds one or two quasars at a time
+        per_step = 896 if (k == 20 and not extra) else (7680 if k == 20 else 29696)
+        many = gp.process_qsos(model, samples, spectra, log_priors=lp, max_quasars_per_batch=len(spectra),
+                               params=gp.Parameters(record_pool_bytes=150 * per_step, **extra))
+        for key in one:
+            np.testing.assert_array_equal(one[key], many[key], err_msg=f"{key} k={k} {extra}")
+
+
 def test_batch_reload_and_destroy_order(model20):
     """gpdla_batch_reload re-fills a batch in place; a batch may outlive its context (it is
     orphaned, not left with a dangling pointer); using it then is an error, destroying it is not."""

@@ -94,10 +94,11 @@ def test_chunks_recombine_to_the_whole_run(tmp_path, md):
 
 
 def test_batch_size_defaults():
-    per_q = record_bytes_per_quasar(1500, 20)
-    assert 2.8e6 < per_q < 3.4e6  # 2.9 MB of step records + the interpolated rows
+    assert 0.33e6 < record_bytes_per_quasar(1500, 20) < 0.4e6          # slim records: 896 B per K-step
+    assert 2.8e6 < record_bytes_per_quasar(1500, 20, slim=False) < 3.0e6
+    assert 11e6 < record_bytes_per_quasar(1500, 40) < 11.3e6
     assert default_batch_size(2048, 1500, 20, 10000, 3) == 256
-    assert default_batch_size(100, 1500, 20, 10000, 3) == 100 or default_batch_size(100, 1500, 20, 10000, 3) == 128
+    assert default_batch_size(100, 1500, 20, 10000, 3) in (100, 128)
     assert default_batch_size(10 ** 6, 1500, 20, 10000, 3) == 4096
-    # memory-bound case: k = 40 records are 29 KB per step
-    assert default_batch_size(10 ** 6, 1500, 40, 10000, 3, budget_bytes=8 * 2 ** 30) < 300
+    # memory-bound case: a small HBM budget
+    assert default_batch_size(10 ** 6, 1500, 40, 10000, 3, budget_bytes=2 ** 30) < 800
