@@ -357,21 +357,18 @@ def test_map_columns_of_the_evidence_kernel(model20):
     assert out3["MAP_inds"][0] == out["MAP_inds"][0]
 
 
-def test_fp32_contraction_study_variant(model20):
+def test_fp32_contraction_study_variant_vs_oracle(oracle, model20):
     """BASELINE config 5: contraction on the fp32 matrix cores, the rest in fp64.  Not parity-grade:
-    the test only bounds its deviation from the fp64 path (k = 20 and the single-wave k = 40 form)."""
-    for k, model in ((20, model20), (40, synthetic.make_model(40))):
-        samples = synthetic.make_samples(300)
-        spectra = synthetic.make_spectra(2, 500, model, first_index=300)
-        lp = flat_priors(2)
-        ref = gp.process_qsos(model, samples, spectra, log_priors=lp)
-        got = gp.process_qsos(model, samples, spectra, log_priors=lp,
-                              params=gp.Parameters(contraction_precision=1))
-        d = np.abs(got["sample_log_likelihoods_dla"] - ref["sample_log_likelihoods_dla"])
-        scale = np.abs(ref["sample_log_likelihoods_dla"]).max()
-        assert np.isfinite(got["sample_log_likelihoods_dla"]).all()
-        assert d.max() < 1e-3 * scale, (k, d.max(), scale)   # fp32 accumulation over n pixels
-        assert np.abs(got["min_z_dlas"] - ref["min_z_dlas"]).max() == 0
+    its distance from the ORACLE is bounded at k = 20 here (the k = 40 form: test_gpu_configs.py)."""
+    samples = synthetic.make_samples(96)
+    sp = synthetic.make_spectrum(300, 500, model20)
+    got = gp.process_qsos(model20, samples, [sp], log_priors=flat_priors(1),
+                          params=gp.Parameters(contraction_precision=1))
+    ref = run_oracle(oracle, model20, samples, sp)
+    d = np.abs(got["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"])
+    assert np.isfinite(got["sample_log_likelihoods_dla"]).all()
+    assert d.max() < 0.5, d.max()   # fp32 accumulation over n pixels: ~1e-2 nat on values of 10^3
+    assert got["min_z_dlas"][0] == ref["min_z_dla"]
 
 
 def test_tiny_and_odd_shapes(oracle, model20):
