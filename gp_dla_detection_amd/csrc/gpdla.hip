@@ -1389,9 +1389,13 @@ struct gpdla_training {
   double *d_x = nullptr, *d_g = nullptr, *d_omega2 = nullptr, *d_f = nullptr;
   int32_t *d_flag = nullptr;
   int64_t x_capacity = 0;
+  // one-block-per-slot path (k > 20, GPDLA_TRAIN_LEGACY): per-slot copies of [g | f], summed in order
+  double *d_slots = nullptr;
+  int64_t slots_capacity = 0;
   // workspace of the matrix-core path (training_mfma_kernels.hpp): its sizes do not depend on k.
   // ws_ready is set only after every allocation, the stream and the kernel attributes succeeded.
   bool ws_ready = false;
+  int ws_class = 0;  // rank class the workspace was sized for (20 or 40)
   double *h_stage = nullptr;  // pinned host staging for x (in) and [g | f | flag] (out)
   int64_t stage_capacity = 0;
   // one evaluation = H2D of x, nine kernels, D2H of [g | f | flag]: captured once per k into a
@@ -1442,7 +1446,7 @@ void gpdla_training_destroy(gpdla_training *t) {
   (void)hipDeviceSynchronize();
   training_free_workspace(t);  // graph, then stream, then the buffers the graph pointed at
   for (void *p : {(void *)t->d_flux, (void *)t->d_lya, (void *)t->d_noise, (void *)t->d_x, (void *)t->d_g,
-                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag, (void *)t->d_loglya})
+                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag, (void *)t->d_loglya, (void *)t->d_slots})
     dev_free(p);
   if (t->h_stage) (void)hipHostFree(t->h_stage);
   delete t;
@@ -1509,10 +1513,13 @@ TrainDims train_dims(const gpdla_training *t, int k) {
   return d;
 }
 
-// One evaluation of objective.m:12-75 on the matrix cores (k <= 20), enqueued on `st`: H2D of x
-// from the pinned staging buffer, the kernels, D2H of [g | f | flag] into it.
+// One evaluation of objective.m:12-75 on the matrix cores, enqueued on `st`: H2D of x from the pinned
+// staging buffer, the kernels, D2H of [g | f | flag] into it.  KMAX: rank class (20 or 40).
+template <int KMAX>
 int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
+  using K = TrC<KMAX>;
   const TrainDims d = train_dims(t, k);
+  const int64_t strideM = (d.T + kTrChunk) * kTrGroupD, strideD = (d.TQ + kTrChunk) * kTrGroupD;
   const int64_t G = t->G, nx = G * (k + 1) + 3;
   HIP_TRY(hipMemcpyAsync(t->d_x, t->h_stage, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(t->d_flag, 0, sizeof(int32_t), st));
@@ -1541,7 +1548,8 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   ra.M = t->d_x;
   ra.recM = t->d_recM;
   ra.recP = t->d_recP;
-  hipLaunchKernelGGL(k_train_records, dim3(1024), dim3(256), 0, st, ra);
+  ra.group_stride = strideM;
+  hipLaunchKernelGGL(k_train_records<KMAX>, dim3(1024), dim3(256), 0, st, ra);
   TrainContractArgs ca;  // B_q, t_q: rows = quasars, steps over pixels
   ca.Aw = t->d_wA;
   ca.Au = t->d_uA;
@@ -1549,8 +1557,12 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   ca.R = d.NQ16;
   ca.steps = d.T;
   ca.nsplit = d.H;
+  ca.groups = K::Groups;
+  ca.w_tiles = K::W;
+  ca.cols = K::Cols;
+  ca.group_stride = strideM;
   ca.out = t->d_partB;
-  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
+  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H * K::Groups)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
   TrainFactorArgs fa;
   fa.d = d;
   fa.partB = t->d_partB;
@@ -1559,15 +1571,17 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   fa.recE = t->d_recE;
   fa.nlogp = t->d_nlogp;
   fa.not_pd = t->d_flag;
-  hipLaunchKernelGGL(k_train_factor<20>, dim3((unsigned)(d.NQ16 * 16 / kTrFQ)), dim3(kTrFQ * 64), 0, st, fa);
+  fa.group_stride = strideD;
+  hipLaunchKernelGGL(k_train_factor<KMAX>, dim3((unsigned)(d.NQ16 * 16 / K::FQ)), dim3(K::FQ * 64), 0, st, fa);
   ca.Aw = t->d_wB;  // dM: rows = pixels, steps over quasars
   ca.Au = t->d_uB;
   ca.Brec = t->d_recD;
   ca.R = d.PG;
   ca.steps = d.TQ;
   ca.nsplit = d.H2;
+  ca.group_stride = strideD;
   ca.out = t->d_partD;
-  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.PG + kTrCWaves - 1) / kTrCWaves) * d.H2)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
+  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.PG + kTrCWaves - 1) / kTrCWaves) * d.H2 * K::Groups)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
   TrainCoreArgs co;
   co.d = d;
   co.recP = t->d_recP;
@@ -1579,7 +1593,10 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   co.scal = t->d_scal;
   co.partcol = t->d_partcol;
   co.partsc = t->d_partsc;
-  hipLaunchKernelGGL(k_train_core, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), kTrCoreLds, st, co);
+  if (KMAX <= 20)
+    hipLaunchKernelGGL(k_train_core, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), kTrCoreLds, st, co);
+  else
+    hipLaunchKernelGGL(k_train_core_wide, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), 0, st, co);
   TrainFinishArgs fi;
   fi.d = d;
   fi.M = t->d_x;
@@ -1592,29 +1609,33 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   fi.flag_out = t->d_g + nx + 1;
   fi.scal = t->d_scal;
   fi.g = t->d_g;
-  hipLaunchKernelGGL(k_train_finish, dim3((unsigned)(G + 1)), dim3(256), 0, st, fi);
+  hipLaunchKernelGGL(k_train_finish<KMAX>, dim3((unsigned)(G + 1)), dim3(256), 0, st, fi);
   HIP_TRY(hipMemcpyAsync(t->h_stage, t->d_g, (size_t)(nx + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
   return GPDLA_OK;
 }
 
-// objective.m:12-75 on the matrix cores (k <= 20): value and gradient, deterministic.  x is in the
-// pinned staging buffer on entry; [g | f | flag] is there on return.
+// objective.m:12-75 on the matrix cores: value and gradient, deterministic.  x is in the pinned
+// staging buffer on entry; [g | f | flag] is there on return.  The workspace is sized by the rank
+// class (k <= 20: one tile group; k <= 40: four) and rebuilt when the class changes.
 int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
   const TrainDims d = train_dims(t, k);
   const int64_t G = t->G, nx = G * (k + 1) + 3;
+  const int kc = k <= 20 ? 20 : 40;
+  const int groups = kc == 20 ? TrC<20>::Groups : TrC<40>::Groups, cols = kc == 20 ? TrC<20>::Cols : TrC<40>::Cols,
+            ks = kc == 20 ? TrC<20>::Ks : TrC<40>::Ks;
   int rc;
-  if (!t->ws_ready) {
-    training_free_workspace(t);  // whatever an earlier, failed attempt left behind
+  if (!t->ws_ready || t->ws_class != kc) {
+    training_free_workspace(t);  // another class's workspace, or what an earlier, failed attempt left behind
     const size_t tiled = (size_t)d.NQ16 * d.T * 64;
     auto setup = [&]() -> int {
     if ((rc = dev_alloc(&t->d_wA, tiled)) || (rc = dev_alloc(&t->d_uA, tiled)) ||
         (rc = dev_alloc(&t->d_wB, (size_t)d.PG * d.TQ * 64)) || (rc = dev_alloc(&t->d_uB, (size_t)d.PG * d.TQ * 64)) ||
         (rc = dev_alloc(&t->d_part1, (size_t)d.NQ16 * 16 * d.PB * 3)) ||
-        (rc = dev_alloc(&t->d_recM, (size_t)(d.T + kTrChunk) * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recP, (size_t)d.PG * kTrKs * 64)) ||
-        (rc = dev_alloc(&t->d_partB, (size_t)d.NQ16 * d.H * 16 * kTrCols)) ||
-        (rc = dev_alloc(&t->d_recD, (size_t)(d.TQ + kTrChunk) * kTrTiles * 64)) || (rc = dev_alloc(&t->d_recE, (size_t)d.NQ16 * kTrKs * 64)) ||
+        (rc = dev_alloc(&t->d_recM, (size_t)groups * (d.T + kTrChunk) * kTrGroupD)) || (rc = dev_alloc(&t->d_recP, (size_t)d.PG * ks * 64)) ||
+        (rc = dev_alloc(&t->d_partB, (size_t)d.NQ16 * d.H * 16 * cols)) ||
+        (rc = dev_alloc(&t->d_recD, (size_t)groups * (d.TQ + kTrChunk) * kTrGroupD)) || (rc = dev_alloc(&t->d_recE, (size_t)d.NQ16 * ks * 64)) ||
         (rc = dev_alloc(&t->d_nlogp, (size_t)d.NQ16 * 16)) ||
-        (rc = dev_alloc(&t->d_partD, (size_t)d.PG * d.H2 * 16 * kTrCols)) ||
+        (rc = dev_alloc(&t->d_partD, (size_t)d.PG * d.H2 * 16 * cols)) ||
         (rc = dev_alloc(&t->d_partcol, (size_t)d.PG * d.GS * 16)) || (rc = dev_alloc(&t->d_partsc, (size_t)d.PG * d.GS * 3)) ||
         (rc = dev_alloc(&t->d_scal, 3)))
       return rc;
@@ -1629,13 +1650,17 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
       training_free_workspace(t);
       return rc;
     }
+    // the chunk padding behind each tile group of recM / recD is read (never used) by the last chunk copy
+    HIP_TRY(hipMemset(t->d_recM, 0, (size_t)groups * (d.T + kTrChunk) * kTrGroupD * sizeof(double)));
+    HIP_TRY(hipMemset(t->d_recD, 0, (size_t)groups * (d.TQ + kTrChunk) * kTrGroupD * sizeof(double)));
     t->ws_ready = true;
+    t->ws_class = kc;
   }
   if (!t->graph || t->graph_k != k) {  // capture the evaluation once per k
     training_drop_graph(t);
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(t->stream, hipStreamCaptureModeThreadLocal));
-    rc = training_enqueue_mfma(t, k, t->stream);
+    rc = kc == 20 ? training_enqueue_mfma<20>(t, k, t->stream) : training_enqueue_mfma<40>(t, k, t->stream);
     hipError_t e = hipStreamEndCapture(t->stream, &graph);
     if (rc) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -1679,15 +1704,25 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&t->h_stage), (size_t)(nx + 2) * sizeof(double), hipHostMallocDefault));
     t->x_capacity = nx;
   }
-  // k <= 20: the three contractions on the matrix cores, ordered (deterministic) sums, one graph
-  // launch per evaluation.  GPDLA_TRAIN_LEGACY=1 (diagnostic) or k > 20: one block per quasar,
-  // fp64 atomics into g.
+  // The three contractions on the matrix cores, ordered (deterministic) sums, one graph launch per
+  // evaluation (k <= 20: one 16-tile group per contraction step; 20 < k <= 40: four).
+  // GPDLA_TRAIN_LEGACY=1 (diagnostic cross-check): one block per slot of quasars, each slot adding
+  // into its own copy of g, slots summed in order -- deterministic too (round 1 used fp64 atomics).
   static const bool legacy = std::getenv("GPDLA_TRAIN_LEGACY") != nullptr;
   std::memcpy(t->h_stage, x, (size_t)nx * sizeof(double));
-  if (k <= 20 && !legacy) return training_objective_mfma(t, k, f, g);
+  if (!legacy) return training_objective_mfma(t, k, f, g);
+  const int num_slots = (int)std::min<int64_t>(t->nq, 512);
+  const int64_t slot_n = nx + 1;  // [g | f]
+  if ((int64_t)num_slots * slot_n > t->slots_capacity) {
+    dev_free(t->d_slots);
+    t->d_slots = nullptr;
+    t->slots_capacity = 0;
+    int rc = dev_alloc(&t->d_slots, (size_t)num_slots * slot_n);
+    if (rc) return rc;
+    t->slots_capacity = (int64_t)num_slots * slot_n;
+  }
   HIP_TRY(hipMemcpy(t->d_x, t->h_stage, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(t->d_g, 0, (size_t)nx * sizeof(double)));
-  HIP_TRY(hipMemset(t->d_f, 0, sizeof(double)));
+  HIP_TRY(hipMemset(t->d_slots, 0, (size_t)num_slots * slot_n * sizeof(double)));
   HIP_TRY(hipMemset(t->d_flag, 0, sizeof(int32_t)));
   hipLaunchKernelGGL(k_training_omega2, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, 0,
                      t->d_x + G * k, G, t->d_omega2);
@@ -1703,18 +1738,20 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
   a.c_0 = std::exp(x[G * (k + 1)]);       // objective.m:30-32
   a.tau_0 = std::exp(x[G * (k + 1) + 1]);
   a.beta = std::exp(x[G * (k + 1) + 2]);
-  a.f = t->d_f;
-  a.g = t->d_g;
+  a.slots = t->d_slots;
   a.not_pd = t->d_flag;
   const size_t lds = training_lds_doubles(G, k) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "training kernel needs %zu B of LDS", lds);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_training_loss),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_training_loss, dim3((unsigned)t->nq), dim3(256), lds, 0, a);
+  hipLaunchKernelGGL(k_training_loss, dim3((unsigned)num_slots), dim3(256), lds, 0, a);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_training_reduce, dim3((unsigned)((slot_n + 255) / 256)), dim3(256), 0, 0, t->d_slots,
+                     num_slots, slot_n, t->d_g);
   HIP_TRY(hipGetLastError());
   int32_t flag = 0;
   HIP_TRY(hipMemcpy(g, t->d_g, (size_t)nx * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(f, t->d_f, sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(f, t->d_g + nx, sizeof(double), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&flag, t->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost));
   if (flag) return fail(GPDLA_ERR_NOT_POSITIVE_DEFINITE, "B = I + M' D^-1 M not positive definite for some quasar");
   // priors of Kim et al. (2007) on tau0 and beta, gradient only (objective.m:59-71)

@@ -7,8 +7,12 @@
 //   K^-1 y = D^-1 (y - M B^-1 M' D^-1 y)
 //   K^-1 M = D^-1 M B^-1            (spectrum_loss.m:55 with C M = I - B^-1 substituted)
 //   diag K^-1 = d^-1 - d^-2 m_p' B^-1 m_p                        (:59)
-// and the gradients of :56-74 accumulated into g with fp64 atomics (25 k addresses, 10^4 adders
-// each: the sums are order-dependent in the last bits, which an L-BFGS caller does not see).
+// and the gradients of :56-74.  Deterministic since round 3: a block is a SLOT that walks quasars
+// slot, slot + S, ... in order and adds each one's gradient into the slot's own copy of g (every
+// address is touched by one thread of the block, always the same one), and k_training_reduce sums
+// the slots in order -- round 1 accumulated g with fp64 atomics, whose order changed the last bits
+// from run to run.  Used for 20 < k <= 40 (the matrix-core path of training_mfma_kernels.hpp
+// takes k <= 20) and as its cross-check (GPDLA_TRAIN_LEGACY=1).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,8 +30,7 @@ struct TrainingArgs {
   const double *M;        // [G x k] column-major (the first G k entries of x)
   const double *omega2;   // [G] exp(2 log omega), objective.m:29
   double c_0, tau_0, beta;
-  double *f;              // scalar accumulator
-  double *g;              // [G (k+1) + 3] accumulator, layout of x (objective.m:73)
+  double *slots;          // [num_slots][G (k+1) + 4]: per slot g in the layout of x (objective.m:73), then f; zeroed by the host
   int32_t *not_pd;        // set to 1 if some B is not positive definite (chol would throw, :42)
 };
 
@@ -40,9 +43,8 @@ __host__ __device__ constexpr size_t training_lds_doubles(int64_t G, int k) {
   return (size_t)(3 * G + 2 * k * k + 3 * k + 8) +
          (size_t)(2 * k * kTrainChunkStride > k * 256 ? 2 * k * kTrainChunkStride : k * 256);
 }
-__global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
-  extern __shared__ double sm[];
-  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void training_one_quasar(const TrainingArgs &a, const int q, double *sm, double *gs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = a.k;
   const int64_t G = a.G;
   double *s_dinv = sm, *s_y = s_dinv + G, *s_kiy = s_y + G;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
       for (int e = 0; e < k; ++e) mb = fma(s_mrow[e * 256 + tid], s_Binv[e * k + c], mb);
       mBm = fma(mb, s_mrow[c * 256 + tid], mBm);
       const double dM = dinv * mb - kiy * s_g[c];                     // :55-56
-      atomicAdd(a.g + p + (int64_t)c * G, dM);
+      gs[p + (int64_t)c * G] += dM;
     }
     const double diag = dinv - dinv * dinv * mBm;                     // :59
     const double od = a.tau_0 * pow(Z[p], a.beta);
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
     const double sf = 1 - ab + a.c_0;
     const double om = a.omega2[p];
     const double core = kiy * kiy - diag;
-    atomicAdd(a.g + G * k + p, -(om * (sf * sf)) * core);             // :62
+    gs[G * k + p] += -(om * (sf * sf)) * core;                        // :62
     double da = a.c_0 * om * sf;                                      // :65
     gc -= core * da;                                                  // :66
     da = om * sf * od * ab;                                           // :69
@@ -282,11 +284,29 @@ __global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
   gb = block_sum(gb);
   if (tid == 0) {
     const double nlog_p = 0.5 * (quad + logd + 2 * s_red[4] + cnt * log_2pi);  // :48-52
-    atomicAdd(a.f, nlog_p);
-    atomicAdd(a.g + G * (k + 1), gc);
-    atomicAdd(a.g + G * (k + 1) + 1, gt);
-    atomicAdd(a.g + G * (k + 1) + 2, gb);
+    gs[G * (k + 1) + 3] += nlog_p;
+    gs[G * (k + 1)] += gc;
+    gs[G * (k + 1) + 1] += gt;
+    gs[G * (k + 1) + 2] += gb;
   }
+}
+
+__global__ __launch_bounds__(256) void k_training_loss(TrainingArgs a) {
+  extern __shared__ double sm[];
+  double *gs = a.slots + (int64_t)blockIdx.x * (a.G * (a.k + 1) + 4);
+  for (int64_t q = blockIdx.x; q < a.nq; q += gridDim.x) {
+    training_one_quasar(a, (int)q, sm, gs);
+    __syncthreads();  // the LDS arrays are reused by the next quasar
+  }
+}
+
+// out[e] = Sum over the slots, in slot order, of slots[s][e], e < n (g, then f behind it)
+__global__ void k_training_reduce(const double *slots, int num_slots, int64_t n, double *out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double v = 0.0;
+  for (int s = 0; s < num_slots; ++s) v += slots[(int64_t)s * n + e];
+  out[e] = v;
 }
 
 // omega2 = exp(2 log omega), objective.m:29

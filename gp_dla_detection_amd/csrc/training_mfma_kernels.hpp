@@ -37,9 +37,28 @@
 
 namespace gpdla {
 
-constexpr int kTrW = 14, kTrU = 2, kTrTiles = kTrW + kTrU;  // B tiles per contraction step
-constexpr int kTrCols = kTrTiles * 16;                      // 256 columns: 224 vech + 32 projection
-constexpr int kTrKsW = 53, kTrKsU = 5, kTrKs = kTrKsW + kTrKsU;  // column steps of the core contraction
+// Rank classes.  A contraction step carries 16-tile GROUPS of B tiles (one group per wave: 16
+// accumulator tiles = 128 registers): k <= 20 has one group -- 14 vech tiles (224 columns >= 210) and
+// 2 projection tiles; k <= 40 has four -- 52 vech tiles (832 >= 820), 3 projection tiles, 9 of
+// padding.  Columns of [vech | v]: vech at 0 .. 16 W, v at 16 W + c.  The core contraction walks the
+// same columns four at a time: KsW steps of vech, KsU steps of v (padded to an even count so that a
+// quasar group's operands are a whole number of KiB).
+template <int KMAX> struct TrK;
+template <> struct TrK<20> {
+  static constexpr int W = 14, U = 2, Groups = 1, KsW = 53, KsU = 5, FQ = 8;
+};
+template <> struct TrK<40> {
+  static constexpr int W = 52, U = 3, Groups = 4, KsW = 205, KsU = 11, FQ = 4;
+};
+template <int KMAX> struct TrC : TrK<KMAX> {
+  static constexpr int Tiles = 16 * TrK<KMAX>::Groups;          // B tiles per contraction step
+  static constexpr int Cols = 16 * Tiles;                       // columns of a contraction's output row
+  static constexpr int Ks = TrK<KMAX>::KsW + TrK<KMAX>::KsU;    // column steps of the core contraction
+  static_assert(Ks % 2 == 0, "a quasar group's operands are a whole number of KiB");
+  static_assert(16 * TrK<KMAX>::W >= KMAX * (KMAX + 1) / 2 && 16 * TrK<KMAX>::U >= KMAX, "columns fit");
+  static_assert(4 * TrK<KMAX>::KsW >= KMAX * (KMAX + 1) / 2 && 4 * TrK<KMAX>::KsU >= KMAX, "column steps fit");
+};
+constexpr int kTrGroupD = 16 * 64;  // doubles of one tile group of one step
 
 struct TrainDims {
   int64_t nq, G;      // quasars, pixels
@@ -145,13 +164,14 @@ __global__ __launch_bounds__(256) void k_train_prepare(TrainPrepareArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // k_train_records: from M (G x k column-major)
-// recM: [T][16 tiles][jj = pixel % 4][col]   B[pixel 4t+jj][column 16c+col] of [vech(m m') | m]
-// recP: [PG][58 column steps][jj][col]        B[column 4ks+jj][pixel 16pt+col], vech then m
+// recM: [group][T + pad][16 tiles][jj = pixel % 4][col]   B[pixel 4t+jj][column] of [vech(m m') | m]
+// recP: [PG][Ks column steps][jj][col]                     B[column 4ks+jj][pixel 16pt+col], vech then m
 // ------------------------------------------------------------------------------------------
 struct TrainRecordsArgs {
   TrainDims d;
   const double *M;
   double *recM, *recP;
+  int64_t group_stride;  // doubles between the tile groups of recM: (T + chunk padding) * 16 * 64
 };
 
 __device__ __forceinline__ double train_col_value(const double *M, int64_t G, int k, int64_t p, int kind, int idx) {
@@ -166,69 +186,79 @@ __device__ __forceinline__ double train_col_value(const double *M, int64_t G, in
   return idx < k ? M[p + (int64_t)idx * G] : 0.0;
 }
 
+template <int KMAX>
 __global__ void k_train_records(TrainRecordsArgs a) {
+  using K = TrC<KMAX>;
   const TrainDims &D = a.d;
-  const int64_t nM = D.T * kTrTiles * 64, nP = D.PG * kTrKs * 64;
+  const int64_t nM = D.T * K::Tiles * 64, nP = D.PG * K::Ks * 64;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nM + nP; e += (int64_t)gridDim.x * blockDim.x) {
     if (e < nM) {
-      const int l = (int)(e & 63), c = (int)((e >> 6) % kTrTiles);
-      const int64_t t = (e >> 6) / kTrTiles;
+      const int l = (int)(e & 63), c = (int)((e >> 6) % K::Tiles);
+      const int64_t t = (e >> 6) / K::Tiles;
       const int jj = l >> 4, col = l & 15;
-      a.recM[e] = c < kTrW ? train_col_value(a.M, D.G, D.k, 4 * t + jj, 0, 16 * c + col)
-                           : train_col_value(a.M, D.G, D.k, 4 * t + jj, 1, 16 * (c - kTrW) + col);
+      const double v = c < K::W ? train_col_value(a.M, D.G, D.k, 4 * t + jj, 0, 16 * c + col)
+                                : train_col_value(a.M, D.G, D.k, 4 * t + jj, 1, 16 * (c - K::W) + col);
+      a.recM[(c >> 4) * a.group_stride + (t * 16 + (c & 15)) * 64 + l] = v;
     } else {
       const int64_t e2 = e - nM;
-      const int l = (int)(e2 & 63), ks = (int)((e2 >> 6) % kTrKs);
-      const int64_t pt = (e2 >> 6) / kTrKs;
+      const int l = (int)(e2 & 63), ks = (int)((e2 >> 6) % K::Ks);
+      const int64_t pt = (e2 >> 6) / K::Ks;
       const int jj = l >> 4, col = l & 15;
-      a.recP[e2] = ks < kTrKsW ? train_col_value(a.M, D.G, D.k, 16 * pt + col, 0, 4 * ks + jj)
-                               : train_col_value(a.M, D.G, D.k, 16 * pt + col, 1, 4 * (ks - kTrKsW) + jj);
+      a.recP[e2] = ks < K::KsW ? train_col_value(a.M, D.G, D.k, 16 * pt + col, 0, 4 * ks + jj)
+                               : train_col_value(a.M, D.G, D.k, 16 * pt + col, 1, 4 * (ks - K::KsW) + jj);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_train_contract: out[R][h][16 rows][256 columns] = Sum over this split's steps of
-// [a_w x 14 tiles | a_u x 2 tiles] (rows x 4) . Brec (4 x 256).  A block is 4 waves = 4 row groups
-// that walk the SAME steps (split h), so the B records are staged once per block: chunks of 4
-// steps, double-buffered in LDS by the sweep's asynchronous global->LDS copy (glds16), one
-// barrier per chunk.  64 KiB of LDS per block: two blocks share a CU, so a SIMD always has a wave
-// of the other block to run while one waits at its barrier.  The A operands (512 contiguous bytes
-// per wave and step) come straight from global memory, one chunk ahead.
+// k_train_contract: out[R][h][16 rows][cols] = Sum over this split's steps of
+// [a_w x W tiles | a_u x U tiles] (rows x 4) . Brec (4 x cols).  A wave owns 16 rows and ONE tile
+// group (16 accumulator tiles); a block is 4 waves = 4 row groups that walk the SAME steps (split
+// h) of the SAME tile group, so that group's B records are staged once per block: chunks of 4
+// steps, double-buffered in LDS by the sweep's asynchronous global->LDS copy, one barrier per
+// chunk.  64 KiB of LDS per block: two blocks share a CU, so a SIMD always has a wave of the other
+// block to run while one waits at its barrier.  The A operands (512 contiguous bytes per wave and
+// step) come straight from global memory, one chunk ahead.
 // ------------------------------------------------------------------------------------------
 struct TrainContractArgs {
   const double *Aw, *Au;   // [R][steps][64]
-  const double *Brec;      // [steps][16][64]
+  const double *Brec;      // [groups][steps + pad][16][64]
   int64_t R, steps;
   int32_t nsplit;
-  double *out;             // [R][nsplit][16][256]
+  int32_t groups, w_tiles, cols;  // tile groups; tiles (over all groups) that take a_w; output row length
+  int64_t group_stride;    // doubles between the tile groups of Brec
+  double *out;             // [R][nsplit][16][cols]
 };
 constexpr int kTrChunk = 4;                             // steps per staged chunk
-constexpr int kTrRecD = kTrTiles * 64;                  // doubles per step record
 constexpr int kTrCWaves = 4;                            // row groups (waves) per block
-constexpr size_t kTrContractLds = 2 * kTrChunk * kTrRecD * sizeof(double);  // 64 KiB
+constexpr size_t kTrContractLds = 2 * kTrChunk * kTrGroupD * sizeof(double);  // 64 KiB
 
-__global__ __launch_bounds__(kTrCWaves * 64) void k_train_contract(TrainContractArgs a) {
-  extern __shared__ double smem[];
+// NW: tiles of the block's group that take a_w (compile-time: the A operand of every MFMA is then
+// a fixed register, not a select)
+template <int NW>
+__device__ __forceinline__ void train_contract_body(const TrainContractArgs &a, double *smem, int tg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t rb = blockIdx.x / a.nsplit;
-  const int h = (int)(blockIdx.x % a.nsplit);
+  const int64_t bx = blockIdx.x / a.groups;
+  const int64_t rb = bx / a.nsplit;
+  const int h = (int)(bx % a.nsplit);
   const int64_t r = rb * kTrCWaves + wave;
   const bool active = r < a.R;
+  constexpr int nw = NW;
   const int64_t t0 = (a.steps * h) / a.nsplit, t1 = (a.steps * (h + 1)) / a.nsplit;  // balanced split
   const int nchunks = (int)((t1 - t0 + kTrChunk - 1) / kTrChunk);
-  d4 acc[kTrTiles];
+  d4 acc[16];
 #pragma unroll
-  for (int c = 0; c < kTrTiles; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < 16; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
   const double *aw = a.Aw + ((active ? r : 0) * a.steps) * 64 + lane, *au = a.Au + ((active ? r : 0) * a.steps) * 64 + lane;
+  const double *brec = a.Brec + tg * a.group_stride;
   // whole chunks, copied as per-wave spans (glds_chunk, sweep_kernels.hpp); a chunk that runs past
-  // t1 reads the following steps' records or the kTrChunk records of padding behind the array
-  static_assert((kTrChunk * kTrRecD) % 128 == 0, "a chunk is a whole number of KiB");
+  // t1 reads the following steps' records or the kTrChunk records of padding behind the group
+  static_assert((kTrChunk * kTrGroupD) % 128 == 0, "a chunk is a whole number of KiB");
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const uint32_t smem_lds = __builtin_amdgcn_readfirstlane(lds_address(smem));
   auto issue_chunk = [&](int c) {
-    glds_chunk<kTrChunk * kTrRecD / 128, kTrCWaves>(a.Brec + (t0 + (int64_t)c * kTrChunk) * kTrRecD,
-                                                    smem_lds + (uint32_t)(c & 1) * (uint32_t)(kTrChunk * kTrRecD * 8), wave_s, lane);
+    glds_chunk<kTrChunk * kTrGroupD / 128, kTrCWaves>(brec + (t0 + (int64_t)c * kTrChunk) * kTrGroupD,
+                                                      smem_lds + (uint32_t)(c & 1) * (uint32_t)(kTrChunk * kTrGroupD * 8), wave_s, lane);
   };
   double wn[kTrChunk], un[kTrChunk];
   auto load_a = [&](int c) {
@@ -256,66 +286,76 @@ __global__ __launch_bounds__(kTrCWaves * 64) void k_train_contract(TrainContract
       load_a(c + 1);
       issue_chunk(c + 1);
     }
-    const double *buf = smem + (size_t)(c & 1) * kTrChunk * kTrRecD + lane;
+    const double *buf = smem + (size_t)(c & 1) * kTrChunk * kTrGroupD + lane;
     const int csteps = (int)min((int64_t)kTrChunk, t1 - (t0 + (int64_t)c * kTrChunk));
 #pragma unroll
     for (int tt = 0; tt < kTrChunk; ++tt) {
       if (tt < csteps) {
-        double b[kTrTiles];
+        double b[16];
 #pragma unroll
-        for (int cc = 0; cc < kTrTiles; ++cc) b[cc] = buf[(size_t)(tt * kTrTiles + cc) * 64];
+        for (int cc = 0; cc < 16; ++cc) b[cc] = buf[(size_t)(tt * 16 + cc) * 64];
 #pragma unroll
-        for (int cc = 0; cc < kTrTiles; ++cc)
-          acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < kTrW ? wc[tt] : uc[tt], b[cc], acc[cc], 0, 0, 0);
+        for (int cc = 0; cc < 16; ++cc)
+          acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? wc[tt] : uc[tt], b[cc], acc[cc], 0, 0, 0);
       }
     }
   }
   if (!active) return;
-  // result register rr of tile c: row (lane >> 4) + 4 rr, column 16 c + (lane & 15)
-  double *o = a.out + ((r * a.nsplit + h) * 16) * kTrCols;
+  // result register rr of tile c: row (lane >> 4) + 4 rr, column 16 (16 tg + c) + (lane & 15)
+  double *o = a.out + ((r * a.nsplit + h) * 16) * (int64_t)a.cols + 256 * tg;
   const int jj = lane >> 4, s = lane & 15;
 #pragma unroll
-  for (int c = 0; c < kTrTiles; ++c)
+  for (int c = 0; c < 16; ++c)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) o[(int64_t)(jj + 4 * rr) * kTrCols + 16 * c + s] = acc[c][rr];
+    for (int rr = 0; rr < 4; ++rr) o[(int64_t)(jj + 4 * rr) * a.cols + 16 * c + s] = acc[c][rr];
+}
+
+__global__ __launch_bounds__(kTrCWaves * 64) void k_train_contract(TrainContractArgs a) {
+  extern __shared__ double smem[];
+  const int tg = (int)(blockIdx.x % a.groups);
+  const int nw = max(0, min(16, a.w_tiles - 16 * tg));  // block-uniform: 14 (k <= 20); 16, 16, 16, 4 (k <= 40)
+  if (nw == 16) train_contract_body<16>(a, smem, tg);
+  else if (nw == 14) train_contract_body<14>(a, smem, tg);
+  else train_contract_body<4>(a, smem, tg);
 }
 
 // ------------------------------------------------------------------------------------------
 // k_train_factor: one wave per quasar (padded quasars write zero operands).
-// recD: [TQ][16 tiles][jj = quasar % 4][col]  B[quasar][column] of [vech(T_q) | z_q]   (dM)
-// recE: [NQ16][58][jj = column % 4][s = quasar % 16]  A[quasar][column] of [vech2(T_q) | z_q]  (core)
+// recD: [group][TQ + pad][16 tiles][jj = quasar % 4][col]  B[quasar][column] of [vech(T_q) | z_q]   (dM)
+// recE: [NQ16][Ks][jj = column % 4][s = quasar % 16]       A[quasar][column] of [vech2(T_q) | z_q]  (core)
 // ------------------------------------------------------------------------------------------
 struct TrainFactorArgs {
   TrainDims d;
-  const double *partB;   // [NQ16][H][16][256]
+  const double *partB;   // [NQ16][H][16][Cols]
   const double *part1;   // [16 NQ16][PB][3]
   double *recD, *recE, *nlogp;
   int32_t *not_pd;
+  int64_t group_stride;  // doubles between the tile groups of recD: (TQ + chunk padding) * 16 * 64
 };
 
-constexpr int kTrFQ = 8;  // quasars (waves) per block of k_train_factor
-
 template <int KMAX>
-__global__ __launch_bounds__(kTrFQ * 64) void k_train_factor(TrainFactorArgs a) {
-  // One wave per quasar, 8 quasars per block.  Lane i owns row i of B / L in registers (static
+__global__ __launch_bounds__(TrK<KMAX>::FQ * 64) void k_train_factor(TrainFactorArgs a) {
+  // One wave per quasar, FQ quasars per block.  Lane i owns row i of B / L in registers (static
   // indices: the loops over KMAX are unrolled); pivots and multipliers travel by wave shuffles, L
   // and L^-1 are shared through LDS for the inverse.  No private array is indexed at run time
   // (that would live in scratch memory).  The two operand tilings of [T_q | z_q] are assembled in
-  // LDS and leave the block as contiguous runs (8 of the 16 interleaved quasars of recE, two whole
-  // quasar steps of recD).
+  // LDS and leave the block as contiguous runs (FQ of the 16 interleaved quasars of recE, FQ / 4
+  // whole quasar steps of recD).
   // (s_sum -- the summed partials -- is dead once the rows are in registers and is reused for the
-  // recD rows; the storage of L / L^-1 likewise for the recE rows: 68 KB, two blocks per CU)
-  __shared__ double s_L[kTrFQ][KMAX * KMAX], s_Bi[kTrFQ][KMAX * KMAX], s_sum[kTrFQ][kTrCols], s_t[kTrFQ][KMAX],
-      s_z[kTrFQ][KMAX], s_sc[kTrFQ][4];
-  static_assert(kTrKs * 4 <= KMAX * KMAX, "recE rows must fit the storage of L");
-  double (*s_outD)[kTrCols] = s_sum;
+  // recD rows; the storage of L / L^-1 likewise for the recE rows)
+  using K = TrC<KMAX>;
+  constexpr int FQ = K::FQ;
+  __shared__ double s_L[FQ][KMAX * KMAX], s_Bi[FQ][KMAX * KMAX], s_sum[FQ][K::Cols], s_t[FQ][KMAX],
+      s_z[FQ][KMAX], s_sc[FQ][4];
+  static_assert(K::Ks * 4 <= KMAX * KMAX, "recE rows must fit the storage of L");
+  double (*s_outD)[K::Cols] = s_sum;
   double (*s_outE)[KMAX * KMAX] = s_L;
-  __shared__ uint8_t s_vi[kTrW * 16], s_vj[kTrW * 16];
+  __shared__ uint8_t s_vi[K::W * 16], s_vj[K::W * 16];
   const TrainDims &D = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = D.k;
-  const int64_t q0 = (int64_t)blockIdx.x * kTrFQ, q = q0 + wave;
+  const int64_t q0 = (int64_t)blockIdx.x * FQ, q = q0 + wave;
   const int nb = k * (k + 1) / 2;
-  for (int c = tid; c < kTrW * 16; c += kTrFQ * 64) {
+  for (int c = tid; c < K::W * 16; c += FQ * 64) {
     int i = 0, j = 0;
     if (c < nb) vech_ij(c, &i, &j);
     s_vi[c] = (uint8_t)i;
@@ -329,12 +369,12 @@ __global__ __launch_bounds__(kTrFQ * 64) void k_train_factor(TrainFactorArgs a) 
   bool pd = true;
   double logdiag = 0.0;
   if (real) {
-    // [vech(B - I) | t] = Sum_h partial, in split order; lanes along the 256 columns (coalesced)
-    const double *pb = a.partB + ((g * D.H) * 16 + qs) * kTrCols;
+    // [vech(B - I) | t] = Sum_h partial, in split order; lanes along the columns (coalesced)
+    const double *pb = a.partB + ((g * D.H) * 16 + qs) * (int64_t)K::Cols;
 #pragma unroll
-    for (int e = 0; e < kTrCols / 64; ++e) {
+    for (int e = 0; e < K::Cols / 64; ++e) {
       double v = 0.0;
-      for (int h = 0; h < D.H; ++h) v += pb[(int64_t)h * 16 * kTrCols + e * 64 + lane];
+      for (int h = 0; h < D.H; ++h) v += pb[(int64_t)h * 16 * K::Cols + e * 64 + lane];
       sum[e * 64 + lane] = v;
     }
     if (lane < 3) {
@@ -356,7 +396,7 @@ __global__ __launch_bounds__(kTrFQ * 64) void k_train_factor(TrainFactorArgs a) 
       }
       row[j] = v;
     }
-    const double tl = mine ? sum[kTrW * 16 + lane] : 0.0;
+    const double tl = mine ? sum[K::W * 16 + lane] : 0.0;
     // Cholesky B = L L' (spectrum_loss.m:42), right-looking
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
@@ -441,53 +481,54 @@ __global__ __launch_bounds__(kTrFQ * 64) void k_train_factor(TrainFactorArgs a) 
     a.nlogp[q] = v;  // (nlogp is allocated for the padded quasar count)
   }
   // T = B^-1 + z z' in the two operand tilings (zero for padded / failed quasars)
-  for (int e = lane; e < kTrCols; e += 64) {
+  for (int e = lane; e < K::Cols; e += 64) {
     double v = 0.0;
     if (good) {
-      if (e < kTrW * 16) {
+      if (e < K::W * 16) {
         if (e < nb) v = sBi[s_vi[e] * k + s_vj[e]] + sz[s_vi[e]] * sz[s_vj[e]];
-      } else if (e - kTrW * 16 < k) {
-        v = sz[e - kTrW * 16];
+      } else if (e - K::W * 16 < k) {
+        v = sz[e - K::W * 16];
       }
     }
     s_outD[wave][e] = v;
   }
-  for (int e = lane; e < kTrKs * 4; e += 64) {
+  for (int e = lane; e < K::Ks * 4; e += 64) {
     const int ks = e >> 2, jj = e & 3;
     double v = 0.0;
     if (good) {
-      if (ks < kTrKsW) {
+      if (ks < K::KsW) {
         const int c = 4 * ks + jj;
         if (c < nb) {
           v = sBi[s_vi[c] * k + s_vj[c]] + sz[s_vi[c]] * sz[s_vj[c]];
           if (s_vi[c] != s_vj[c]) v *= 2.0;  // m'T m = Sum_{i>=j} (2 - delta_ij) T_ij m_i m_j
         }
       } else {
-        const int c = 4 * (ks - kTrKsW) + jj;
+        const int c = 4 * (ks - K::KsW) + jj;
         if (c < k) v = sz[c];
       }
     }
     s_outE[wave][e] = v;
   }
   __syncthreads();
-  // recD: [tq][16 tiles][jj = quasar % 4][col]: the block's 8 quasars are two whole quasar steps
-  for (int e = tid; e < 2 * kTrTiles * 64; e += kTrFQ * 64) {
-    const int tql = e / (kTrTiles * 64), r = e % (kTrTiles * 64);
+  // recD: [group][tq][16 tiles][jj = quasar % 4][col]: the block's FQ quasars are FQ / 4 whole quasar steps
+  for (int e = tid; e < (FQ / 4) * K::Tiles * 64; e += FQ * 64) {
+    const int tql = e / (K::Tiles * 64), r = e % (K::Tiles * 64);
     const int c = r >> 6, jj = (r >> 4) & 3, col = r & 15;
-    a.recD[((q0 >> 2) + tql) * kTrTiles * 64 + r] = s_outD[4 * tql + jj][16 * c + col];
+    a.recD[(c >> 4) * a.group_stride + (((q0 >> 2) + tql) * 16 + (c & 15)) * 64 + (r & 63)] =
+        s_outD[4 * tql + jj][16 * c + col];
   }
-  // recE: [g][58][jj = column % 4][s = quasar % 16]: 8 consecutive s per (ks, jj)
+  // recE: [g][Ks][jj = column % 4][s = quasar % 16]: FQ consecutive s per (ks, jj)
   const int64_t g_blk = q0 >> 4;
   const int s0 = (int)(q0 & 15);
-  for (int e = tid; e < kTrKs * 4 * kTrFQ; e += kTrFQ * 64) {
-    const int ql = e & (kTrFQ - 1), kj = e >> 3;  // kj = 4 ks + jj
-    a.recE[g_blk * kTrKs * 64 + (int64_t)kj * 16 + s0 + ql] = s_outE[ql][kj];
+  for (int e = tid; e < K::Ks * 4 * FQ; e += FQ * 64) {
+    const int ql = e % FQ, kj = e / FQ;  // kj = 4 ks + jj
+    a.recE[g_blk * K::Ks * 64 + (int64_t)kj * 16 + s0 + ql] = s_outE[ql][kj];
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_train_core: one wave per (pixel group pt, split gs of the quasar groups).
-// X_qp = m_p' T_q m_p (53 column steps), Y_qp = m_p' z_q (5 column steps) by MFMA, then
+// X_qp = m_p' T_q m_p (KsW column steps), Y_qp = m_p' z_q (KsU column steps) by MFMA, then
 // core_qp and the sums over the wave's quasars: partcol[pt][gs][16] = Sum an core per pixel,
 // partsc[pt][gs][3] = Sum core da for (c0, tau0, beta).
 // ------------------------------------------------------------------------------------------
@@ -498,86 +539,52 @@ struct TrainCoreArgs {
   const double *scal;  // [3] c0, tau0, beta
   double *partcol, *partsc;
 };
-constexpr size_t kTrCoreLds = 2 * kTrKs * 64 * sizeof(double);  // two quasar groups' A operands
+constexpr size_t kTrCoreLds = 2 * TrC<20>::Ks * 64 * sizeof(double);  // k <= 20: two quasar groups' A operands
 
-// A block is 4 waves = 4 pixel groups that walk the SAME quasar groups (split gs): the A operands
-// of a quasar group ([vech2(T_q) | z_q] of its 16 quasars, 29 KB) are staged once per block,
-// double-buffered by glds16; the B operands of the wave's pixel group stay in registers.
-__global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
-  extern __shared__ double smem[];
+// The element-wise gradient terms of one (16 quasars x 16 pixels) tile from X = m'Tm and Y = m'z
+// (result register rr: quasar 16 g + jj + 4 rr, pixel p), accumulated into the wave's sums.
+__device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t g, int64_t p, int jj, bool active,
+                                                double om, double c_0, double tau_0, double beta, const d4 &X4,
+                                                const d4 &Y4, double &col, double &gc, double &gt, double &gb) {
   const TrainDims &D = a.d;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t pblk = blockIdx.x / D.GS;
-  const int gs = (int)(blockIdx.x % D.GS);
-  const int64_t pt = pblk * 4 + wave;
-  const bool active = pt < D.PG;
-  const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;  // balanced split
-  const int jj = lane >> 4, s = lane & 15;
-  const int64_t p = pt * 16 + s;
-  const double c_0 = a.scal[0], tau_0 = a.scal[1], beta = a.scal[2];
-  double bP[kTrKs];
+  double ye[4], lz[4], nv[4];
 #pragma unroll
-  for (int ks = 0; ks < kTrKs; ++ks) bP[ks] = active ? a.recP[(pt * kTrKs + ks) * 64 + lane] : 0.0;
-  const double om = (active && p < D.G) ? a.omega2[p] : 0.0;
-  static_assert((kTrKs * 64) % 128 == 0, "a quasar group's operands are a whole number of KiB");
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const uint32_t smem_lds = __builtin_amdgcn_readfirstlane(lds_address(smem));
-  auto issue_group = [&](int64_t g) {  // (glds_chunk, sweep_kernels.hpp)
-    glds_chunk<kTrKs * 64 / 128, 4>(a.recE + g * kTrKs * 64, smem_lds + (uint32_t)((g - g0) & 1) * (uint32_t)(kTrKs * 64 * 8),
-                                    wave_s, lane);
-  };
-  if (g0 < g1) issue_group(g0);
-  double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
-  for (int64_t g = g0; g < g1; ++g) {
-    glds_wait();
-    __syncthreads();
-    if (g + 1 < g1) issue_group(g + 1);
-    const double *re = smem + (size_t)((g - g0) & 1) * kTrKs * 64 + lane;
-    // two accumulator chains for X (registers: the kernel must stay within 256 per lane so that
-    // two waves share a SIMD), one for Y
-    d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, yv = x0;
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t q = g * 16 + jj + 4 * rr;
+    const bool ok = active && q < D.nq && p < D.G;
+    ye[rr] = ok ? a.flux[q * D.G + p] : NAN;
+    lz[rr] = ok ? a.log_lya_1pz[q * D.G + p] : 0.0;
+    nv[rr] = ok ? a.noise[q * D.G + p] : 1.0;
+  }
 #pragma unroll
-    for (int ks = 0; ks < kTrKsW; ks += 2) {
-      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], x0, 0, 0, 0);
-      if (ks + 1 < kTrKsW) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 1) * 64], bP[ks + 1], x1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int ks = kTrKsW; ks < kTrKs; ++ks)
-      yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], yv, 0, 0, 0);
-    double ye[4], lz[4], nv[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int64_t q = g * 16 + jj + 4 * rr;
-      const bool ok = active && q < D.nq && p < D.G;
-      ye[rr] = ok ? a.flux[q * D.G + p] : NAN;
-      lz[rr] = ok ? a.log_lya_1pz[q * D.G + p] : 0.0;
-      nv[rr] = ok ? a.noise[q * D.G + p] : 1.0;
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {  // result register rr: quasar 16 g + jj + 4 rr, pixel p
-      const double y = ye[rr];
-      if (!isnan(y)) {
-        const double od = tau_0 * fast_rcp(exp_nonpos(-beta * lz[rr]));  // :22 (as k_train_prepare)
-        const double ab = exp_nonpos(-od);                        // :23
-        const double sf = 1 - ab + c_0;                           // :26
-        const double an = om * (sf * sf);                         // :27
-        const double w = fast_rcp(nv[rr] + an);                   // :29-31
-        const double u = w * y;
-        const double X = x0[rr] + x1[rr], Y = yv[rr];
-        const double kiy = u - w * Y;                             // (K^-1 y)_p, :46
-        const double diag = w - w * w * X + w * w * Y * Y;        // (K^-1)_pp = w - w^2 m'B^-1 m, :59
-        const double core = kiy * kiy - diag;
-        col = fma(an, core, col);                                 // :62
-        double da = c_0 * om * sf;                                // :65
-        gc = fma(core, da, gc);                                   // :66
-        da = om * sf * od * ab;                                   // :69
-        gt = fma(core, da, gt);                                   // :70
-        da = da * lz[rr] * beta;                                  // :73
-        gb = fma(core, da, gb);                                   // :74
-      }
+  for (int rr = 0; rr < 4; ++rr) {
+    const double y = ye[rr];
+    if (!isnan(y)) {
+      const double od = tau_0 * fast_rcp(exp_nonpos(-beta * lz[rr]));  // :22 (as k_train_prepare)
+      const double ab = exp_nonpos(-od);                        // :23
+      const double sf = 1 - ab + c_0;                           // :26
+      const double an = om * (sf * sf);                         // :27
+      const double w = fast_rcp(nv[rr] + an);                   // :29-31
+      const double u = w * y;
+      const double X = X4[rr], Y = Y4[rr];
+      const double kiy = u - w * Y;                             // (K^-1 y)_p, :46
+      const double diag = w - w * w * X + w * w * Y * Y;        // (K^-1)_pp = w - w^2 m'B^-1 m, :59
+      const double core = kiy * kiy - diag;
+      col = fma(an, core, col);                                 // :62
+      double da = c_0 * om * sf;                                // :65
+      gc = fma(core, da, gc);                                   // :66
+      da = om * sf * od * ab;                                   // :69
+      gt = fma(core, da, gt);                                   // :70
+      da = da * lz[rr] * beta;                                  // :73
+      gb = fma(core, da, gb);                                   // :74
     }
   }
-  if (!active) return;
+}
+
+__device__ __forceinline__ void train_core_store(const TrainCoreArgs &a, int64_t pt, int gs, int lane, double col,
+                                                 double gc, double gt, double gb) {
+  const TrainDims &D = a.d;
+  const int jj = lane >> 4, s = lane & 15;
   col += __shfl_xor(col, 16);
   col += __shfl_xor(col, 32);
   if (jj == 0) a.partcol[(pt * D.GS + gs) * 16 + s] = col;
@@ -592,6 +599,97 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
     o3[1] = gt;
     o3[2] = gb;
   }
+}
+
+// k <= 20.  A block is 4 waves = 4 pixel groups that walk the SAME quasar groups (split gs): the A
+// operands of a quasar group ([vech2(T_q) | z_q] of its 16 quasars, 29 KB) are staged once per
+// block, double-buffered by glds16; the B operands of the wave's pixel group stay in registers.
+__global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
+  extern __shared__ double smem[];
+  using K = TrC<20>;
+  const TrainDims &D = a.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t pblk = blockIdx.x / D.GS;
+  const int gs = (int)(blockIdx.x % D.GS);
+  const int64_t pt = pblk * 4 + wave;
+  const bool active = pt < D.PG;
+  const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;  // balanced split
+  const int jj = lane >> 4, s = lane & 15;
+  const int64_t p = pt * 16 + s;
+  const double c_0 = a.scal[0], tau_0 = a.scal[1], beta = a.scal[2];
+  double bP[K::Ks];
+#pragma unroll
+  for (int ks = 0; ks < K::Ks; ++ks) bP[ks] = active ? a.recP[(pt * K::Ks + ks) * 64 + lane] : 0.0;
+  const double om = (active && p < D.G) ? a.omega2[p] : 0.0;
+  static_assert((K::Ks * 64) % 128 == 0, "a quasar group's operands are a whole number of KiB");
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t smem_lds = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  auto issue_group = [&](int64_t g) {  // (glds_chunk, sweep_kernels.hpp)
+    glds_chunk<K::Ks * 64 / 128, 4>(a.recE + g * K::Ks * 64, smem_lds + (uint32_t)((g - g0) & 1) * (uint32_t)(K::Ks * 64 * 8),
+                                    wave_s, lane);
+  };
+  if (g0 < g1) issue_group(g0);
+  double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
+  for (int64_t g = g0; g < g1; ++g) {
+    glds_wait();
+    __syncthreads();
+    if (g + 1 < g1) issue_group(g + 1);
+    const double *re = smem + (size_t)((g - g0) & 1) * K::Ks * 64 + lane;
+    // two accumulator chains for X (registers: the kernel must stay within 256 per lane so that
+    // two waves share a SIMD), one for Y
+    d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, yv = x0;
+#pragma unroll
+    for (int ks = 0; ks < K::KsW; ks += 2) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], x0, 0, 0, 0);
+      if (ks + 1 < K::KsW) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 1) * 64], bP[ks + 1], x1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = K::KsW; ks < K::Ks; ++ks)
+      yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], yv, 0, 0, 0);
+    const d4 xs = {x0[0] + x1[0], x0[1] + x1[1], x0[2] + x1[2], x0[3] + x1[3]};
+    train_core_tile(a, g, p, jj, active, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
+  }
+  if (!active) return;
+  train_core_store(a, pt, gs, lane, col, gc, gt, gb);
+}
+
+// 20 < k <= 40: 216 column steps -- too many B operands for the registers and 110 KB of A operands
+// per quasar group -- so both operands of every MFMA come straight from global memory (512
+// contiguous bytes per wave and step, L2 / MALL resident: recE is 34 MB for 5000 quasars), four
+// accumulator chains.  One wave per (pixel group, split); no LDS, no barriers.
+__global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
+  using K = TrC<40>;
+  const TrainDims &D = a.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t pblk = blockIdx.x / D.GS;
+  const int gs = (int)(blockIdx.x % D.GS);
+  const int64_t pt = pblk * 4 + wave;
+  if (pt >= D.PG) return;
+  const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;
+  const int jj = lane >> 4, s = lane & 15;
+  const int64_t p = pt * 16 + s;
+  const double c_0 = a.scal[0], tau_0 = a.scal[1], beta = a.scal[2];
+  const double om = p < D.G ? a.omega2[p] : 0.0;
+  const double *bp = a.recP + pt * K::Ks * 64 + lane;
+  double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
+  for (int64_t g = g0; g < g1; ++g) {
+    const double *re = a.recE + g * K::Ks * 64 + lane;
+    d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, x2 = x0, x3 = x0, yv = x0;
+    for (int ks = 0; ks + 3 < K::KsW; ks += 4) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 1) * 64], bp[(ks + 1) * 64], x1, 0, 0, 0);
+      x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 2) * 64], bp[(ks + 2) * 64], x2, 0, 0, 0);
+      x3 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 3) * 64], bp[(ks + 3) * 64], x3, 0, 0, 0);
+    }
+    for (int ks = K::KsW & ~3; ks < K::KsW; ++ks)
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], x0, 0, 0, 0);
+    for (int ks = K::KsW; ks < K::Ks; ++ks)
+      yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], yv, 0, 0, 0);
+    const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
+                   (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
+    train_core_tile(a, g, p, jj, true, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
+  }
+  train_core_store(a, pt, gs, lane, col, gc, gt, gb);
 }
 
 // exp of the three scalar parameters (objective.m:30-32) and omega2 = exp(2 log omega) (:29): on
@@ -616,7 +714,7 @@ __global__ void k_train_scalars(TrainScalarsArgs a) {
 struct TrainFinishArgs {
   TrainDims d;
   const double *M;
-  const double *partD;    // [PG][H2][16][256]
+  const double *partD;    // [PG][H2][16][Cols]
   const double *partcol;  // [PG][GS][16]
   const double *partsc;   // [PG][GS][3]
   const double *nlogp;    // [16 NQ16]
@@ -626,19 +724,21 @@ struct TrainFinishArgs {
   double *f, *g;          // g: [G (k+1) + 3]
 };
 
+template <int KMAX>
 __global__ __launch_bounds__(256) void k_train_finish(TrainFinishArgs a) {
-  __shared__ double s_a[kTrCols], s_red[256];
+  using K = TrC<KMAX>;
+  __shared__ double s_a[K::Cols], s_red[256];
   const TrainDims &D = a.d;
   const int tid = threadIdx.x, k = D.k;
   const int64_t G = D.G;
   if ((int64_t)blockIdx.x < G) {
     const int64_t p = blockIdx.x, pt = p >> 4;
     const int ps = (int)(p & 15);
-    {  // A_p (vech) and C_p: sum of the quasar splits, in order
-      const double *pd = a.partD + ((pt * D.H2) * 16 + ps) * kTrCols + tid;
+    for (int e = tid; e < K::Cols; e += 256) {  // A_p (vech) and C_p: sum of the quasar splits, in order
+      const double *pd = a.partD + ((pt * D.H2) * 16 + ps) * (int64_t)K::Cols + e;
       double v = 0.0;
-      for (int h = 0; h < D.H2; ++h) v += pd[(int64_t)h * 16 * kTrCols];
-      s_a[tid] = v;
+      for (int h = 0; h < D.H2; ++h) v += pd[(int64_t)h * 16 * K::Cols];
+      s_a[e] = v;
     }
     __syncthreads();
     if (tid < k) {  // dM[p, c] = Sum_e m_p[e] A_p[e, c] - C_p[c]   (:55-56)
@@ -647,7 +747,7 @@ __global__ __launch_bounds__(256) void k_train_finish(TrainFinishArgs a) {
         const int i = e > tid ? e : tid, j = e > tid ? tid : e;
         acc = fma(a.M[p + (int64_t)e * G], s_a[i * (i + 1) / 2 + j], acc);
       }
-      a.g[p + (int64_t)tid * G] = acc - s_a[kTrW * 16 + tid];
+      a.g[p + (int64_t)tid * G] = acc - s_a[K::W * 16 + tid];
     }
     if (tid == 64) {
       double v = 0.0;
