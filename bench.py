@@ -160,6 +160,8 @@ def cpu_baseline(model, samples, spectra, seconds_target=6.0, repeats=3):
                 parallel_efficiency=value / (threads * single),
                 build="gcc -O3 -march=native -fopenmp -ffp-contract=off (oracle/Makefile `timing`); "
                       f"max |delta| vs the checker build {same:.1e}",
+                host=(f"{threads} threads: the CPU quota of this job -- a {info['cpu_quota'] or threads:g}-CPU slice of a "
+                      f"{info['logical_cpus']}-logical-CPU host" if info["cpu_quota"] else f"{threads} threads"),
                 sample=f"{repeats} x {per_repeat} quasar(s) ({n_desc[0]}..{n_desc[-1]} stored pixels) x all {S} "
                        f"samples, {spent_all:.1f} s in total, OpenMP over samples on {threads} threads; "
                        f"single_core_value from {one_count} samples on 1 thread (best of 3)")

@@ -459,14 +459,32 @@ def default_batch_size(num_quasars: int, longest: int, k: int, num_samples: int,
     return max(1, min(cap, want, 4096))
 
 
-def run_pipeline(ctx: "Context", num_blocks: int, inputs, process, download, slots: int = 3):
+def batch_blocks(num_quasars: int, per_batch: int) -> list:
+    """[lo, hi) blocks of a pipelined run.  (Equal blocks: a short first block would start the GPU
+    2 ms earlier, but the slot it leaves behind has to grow when it is re-filled, and a hipFree
+    waits for the sweeps in flight.)"""
+    per_batch = max(1, int(per_batch))
+    return [(lo, min(lo + per_batch, num_quasars)) for lo in range(0, num_quasars, per_batch)]
+
+
+def prefault(*arrays):
+    """Touch every page of freshly allocated output arrays (one write per 4 KiB).  Done on the
+    download thread while the first batch is swept: a device-to-host copy into untouched pageable
+    memory runs at page-fault speed (4 GB/s measured; 10+ once the pages exist)."""
+    for a in arrays:
+        flat = a.reshape(-1)
+        flat[::max(1, 4096 // a.itemsize)] = 0
+
+
+def run_pipeline(ctx: "Context", num_blocks: int, inputs, process, download, slots: int = 3, warm=None):
     """The host loop of process_qsos.m:88 as a three-stage pipeline over HBM-resident batches:
     while batch i is swept, batch i+1 is prepared and uploaded by one thread and batch i-1
     downloaded by another (the library's copy streams run beside the compute stream; ctypes
     releases the GIL inside the calls).  ``inputs(i)`` returns the arguments of ``Context.upload``
     for block i; ``process(i, batch)`` launches its sweep (main thread, in order);
     ``download(i, batch)`` fetches its results.  ``slots`` batches exist at a time and are
-    re-filled in place, so the steady state allocates nothing."""
+    re-filled in place, so the steady state allocates nothing.  ``warm``: a callable run once on the
+    download thread before the first download (e.g. :func:`prefault` of the output arrays)."""
     from concurrent.futures import ThreadPoolExecutor
     if num_blocks <= 0:
         return
@@ -488,6 +506,7 @@ def run_pipeline(ctx: "Context", num_blocks: int, inputs, process, download, slo
 
     try:
         nxt = up_pool.submit(upload, 0)
+        warmed = down_pool.submit(warm) if warm is not None else None
         for i in range(num_blocks):
             batch = nxt.result()
             # upload(i + 1) waits for done[i + 1 - slots]: with one slot that is THIS block's
@@ -500,6 +519,8 @@ def run_pipeline(ctx: "Context", num_blocks: int, inputs, process, download, slo
                 nxt = up_pool.submit(upload, i + 1)
         for f in done:
             f.result()
+        if warmed is not None:
+            warmed.result()
     finally:
         up_pool.shutdown(wait=True)
         down_pool.shutdown(wait=True)
@@ -536,7 +557,7 @@ def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None
     if max_quasars_per_batch is None:
         longest = max((np.asarray(s["wavelengths"]).size for s in spectra), default=1)
         max_quasars_per_batch = default_batch_size(nq, longest, k, S, pipeline_slots)
-    blocks = [(lo, min(lo + max_quasars_per_batch, nq)) for lo in range(0, nq, max_quasars_per_batch)]
+    blocks = batch_blocks(nq, max_quasars_per_batch)
     out = Batch.empty_results(nq, S, with_samples) if nq else {}
     ctx = Context(device, p)
     try:
@@ -547,7 +568,8 @@ def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None
                                 lp_dla[blocks[i][0]:blocks[i][1]]),
                      lambda i, batch: batch.process(),
                      lambda i, batch: batch.download(with_samples, out, blocks[i][0]),
-                     pipeline_slots)
+                     pipeline_slots,
+                     warm=(lambda: prefault(out["sample_log_likelihoods_dla"])) if with_samples and nq else None)
     finally:
         ctx.close()
     out["num_lines"] = p.num_lines
@@ -615,7 +637,7 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
             longest = max((np.asarray(s["wavelengths"]).size for s in spectra), default=1)
             max_quasars_per_batch = default_batch_size(nq, longest, np.asarray(model["M"]).shape[1], S,
                                                        pipeline_slots, multi_models=md + 1)
-        blocks = [(lo, min(lo + max_quasars_per_batch, nq)) for lo in range(0, nq, max_quasars_per_batch)]
+        blocks = batch_blocks(nq, max_quasars_per_batch)
         take = lambda lo, hi: spectra[lo:hi]
     lp_no, lp_lls, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
     lp_dla = lp_dla.reshape(nq, md)
@@ -639,7 +661,9 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
                      lambda i: (take(*blocks[i]), lp_no[blocks[i][0]:blocks[i][1]],
                                 lp_dla[blocks[i][0]:blocks[i][1]], lp_lls[blocks[i][0]:blocks[i][1]]),
                      process, lambda i, batch: batch.download_multi(True, out, blocks[i][0]),
-                     pipeline_slots)
+                     pipeline_slots,
+                     warm=(lambda: prefault(out["sample_log_likelihoods_dla"], out["sample_log_likelihoods_lls"],
+                                            out["base_sample_inds"])) if nq else None)
     finally:
         ctx.close()
     return out

@@ -182,9 +182,12 @@ struct gpdla_batch {
   // capacities (elements) of the device arrays below: gpdla_batch_reload re-fills a batch in
   // place and reallocates only what has grown, so a pipeline's batch slots do no hipMalloc/hipFree
   // (hipFree waits for the whole device) in the steady state
+  // Every array below except the record pool is carved out of ONE device allocation (arena): a
+  // batch slot costs two hipMalloc / hipFree in its life, not eighteen (a hipFree waits for the
+  // whole device; on the PCIe-inclusive path the frees of three slots were 1.5 % of a 2048-quasar run)
+  void *arena = nullptr;
   struct {
-    size_t offsets = 0, wl = 0, flux = 0, nv = 0, z = 0, mask = 0, lp_no = 0, lp_dla = 0, meta = 0, order = 0,
-           pix = 0, Mi = 0, lam = 0, records = 0, sample_ll = 0, ll_no = 0, summary = 0, rec_off = 0;
+    size_t arena = 0, records = 0;  // bytes; elements
   } cap;
   // Record plan (plan_records): the K-step records of the batch's quasars live in ONE pool of at most
   // cfg.record_pool_bytes; quasars are taken in dealing order (h_order: decreasing length) and cut
@@ -441,24 +444,8 @@ void gpdla_batch_destroy(gpdla_batch *b) {
     (void)hipDeviceSynchronize();  // the context (and its streams) went first
   }
   if (b->ev_done) (void)hipEventDestroy(b->ev_done);
-  dev_free(b->d_offsets);
-  dev_free(b->d_wl);
-  dev_free(b->d_flux);
-  dev_free(b->d_nv);
-  dev_free(b->d_z);
-  dev_free(b->d_mask);
-  dev_free(b->d_lp_no);
-  dev_free(b->d_lp_dla);
-  dev_free(b->d_meta);
-  dev_free(b->d_order);
-  dev_free(b->d_pix);
-  dev_free(b->d_Mi);
-  dev_free(b->d_lam);
+  dev_free(b->arena);
   dev_free(b->d_records);
-  dev_free(b->d_sample_ll);
-  dev_free(b->d_ll_no);
-  dev_free(b->d_summary);
-  dev_free(b->d_rec_off);
   delete b->mb;
   delete b;
 }
@@ -544,38 +531,75 @@ int batch_fill(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, int md
   StreamDrain drain{st};  // on every exit: nothing still reads off / meta / order / the caller's arrays
   int rc = GPDLA_OK;
   auto chk = [&](int r) { if (r && !rc) rc = r; };
-  chk(reserve_copy(&b->d_offsets, &b->cap.offsets, off.data(), (size_t)nq + 1, st));
-  chk(reserve_copy(&b->d_wl, &b->cap.wl, sp->wavelengths + base, (size_t)b->total_pix, st));
-  chk(reserve_copy(&b->d_flux, &b->cap.flux, sp->flux + base, (size_t)b->total_pix, st));
-  chk(reserve_copy(&b->d_nv, &b->cap.nv, sp->noise_variance + base, (size_t)b->total_pix, st));
-  chk(reserve_copy(&b->d_mask, &b->cap.mask, sp->pixel_mask + base, (size_t)b->total_pix, st));
-  chk(reserve_copy(&b->d_z, &b->cap.z, sp->z_qsos, (size_t)nq, st));
-  chk(reserve_copy(&b->d_lp_no, &b->cap.lp_no, sp->log_priors_no_dla, (size_t)nq, st));
-  if (!md) {
-    chk(reserve_copy(&b->d_lp_dla, &b->cap.lp_dla, sp->log_priors_dla, (size_t)nq, st));
-  } else {  // multi-DLA batch: [nq][max_dlas] DLA priors + the sub-DLA prior (multi :204-210)
-    delete b->mb;  // result tables are sized by nq: rebuilt by the next gpdla_batch_process_multi
-    b->mb = new MultiBuffers();
-    chk(upload(&b->mb->lp_dla, sp->log_priors_dla, (size_t)nq * md, st));
-    chk(upload(&b->mb->lp_lls, sp->log_priors_lls, (size_t)nq, st));
-  }
-  chk(reserve_copy(&b->d_meta, &b->cap.meta, meta.data(), (size_t)nq, st));
   std::vector<int32_t> order((size_t)nq);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
     return off[x + 1] - off[x] > off[y + 1] - off[y];
   });
-  chk(reserve_copy(&b->d_order, &b->cap.order, order.data(), (size_t)nq, st));
   b->h_order = order;
-  chk(reserve(&b->d_pix, &b->cap.pix, (size_t)rows));
-  chk(reserve(&b->d_Mi, &b->cap.Mi, (size_t)rows * b->k));
-  chk(reserve(&b->d_lam, &b->cap.lam, (size_t)lam));
-  // (the step records are sized by the record class the sweep will use: reserved by launch_prepare)
-  if (!md) {
-    chk(reserve(&b->d_sample_ll, &b->cap.sample_ll, (size_t)nq * b->S));
-    chk(reserve(&b->d_ll_no, &b->cap.ll_no, (size_t)nq));
-    chk(reserve(&b->d_summary, &b->cap.summary, (size_t)nq * GPDLA_SUMMARY_COLS));
+  // lay the arrays out in the arena (256-byte aligned), growing it when this fill needs more
+  size_t need = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = need;
+    need += (std::max<size_t>(bytes, 8) + 255) & ~(size_t)255;
+    return at;
+  };
+  const size_t npx = (size_t)b->total_pix, nqs = (size_t)nq;
+  const size_t o_offsets = take((nqs + 1) * 8), o_wl = take(npx * 8), o_flux = take(npx * 8), o_nv = take(npx * 8),
+               o_mask = take(npx), o_z = take(nqs * 8), o_lp_no = take(nqs * 8), o_lp_dla = take(md ? 8 : nqs * 8),
+               o_meta = take(nqs * sizeof(QuasarMeta)), o_order = take(nqs * 4), o_rec_off = take(nqs * 8),
+               o_pix = take((size_t)rows * sizeof(PixelRow)), o_Mi = take((size_t)rows * b->k * 8),
+               o_lam = take((size_t)lam * 8), o_sll = take(md ? 8 : nqs * b->S * 8), o_ll_no = take(md ? 8 : nqs * 8),
+               o_summary = take(md ? 8 : nqs * GPDLA_SUMMARY_COLS * 8);
+  if (!b->arena || b->cap.arena < need) {
+    dev_free(b->arena);
+    b->arena = nullptr;
+    b->cap.arena = 0;
+    void *p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) return fail(GPDLA_ERR_HIP, "hipMalloc of %zu bytes for a batch failed", need);
+    b->arena = p;
+    b->cap.arena = need;
   }
+  char *base_p = static_cast<char *>(b->arena);
+  auto at = [&](size_t o) { return static_cast<void *>(base_p + o); };
+  b->d_offsets = static_cast<int64_t *>(at(o_offsets));
+  b->d_wl = static_cast<double *>(at(o_wl));
+  b->d_flux = static_cast<double *>(at(o_flux));
+  b->d_nv = static_cast<double *>(at(o_nv));
+  b->d_mask = static_cast<uint8_t *>(at(o_mask));
+  b->d_z = static_cast<double *>(at(o_z));
+  b->d_lp_no = static_cast<double *>(at(o_lp_no));
+  b->d_lp_dla = static_cast<double *>(at(o_lp_dla));
+  b->d_meta = static_cast<QuasarMeta *>(at(o_meta));
+  b->d_order = static_cast<int32_t *>(at(o_order));
+  b->d_rec_off = static_cast<int64_t *>(at(o_rec_off));
+  b->d_pix = static_cast<PixelRow *>(at(o_pix));
+  b->d_Mi = static_cast<double *>(at(o_Mi));
+  b->d_lam = static_cast<double *>(at(o_lam));
+  b->d_sample_ll = static_cast<double *>(at(o_sll));
+  b->d_ll_no = static_cast<double *>(at(o_ll_no));
+  b->d_summary = static_cast<double *>(at(o_summary));
+  auto put = [&](void *dst, const void *src, size_t bytes) -> int {
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    return GPDLA_OK;
+  };
+  chk(put(b->d_offsets, off.data(), (nqs + 1) * 8));
+  chk(put(b->d_wl, sp->wavelengths + base, npx * 8));
+  chk(put(b->d_flux, sp->flux + base, npx * 8));
+  chk(put(b->d_nv, sp->noise_variance + base, npx * 8));
+  chk(put(b->d_mask, sp->pixel_mask + base, npx));
+  chk(put(b->d_z, sp->z_qsos, nqs * 8));
+  chk(put(b->d_lp_no, sp->log_priors_no_dla, nqs * 8));
+  if (!md) {
+    chk(put(b->d_lp_dla, sp->log_priors_dla, nqs * 8));
+  } else {  // multi-DLA batch: [nq][max_dlas] DLA priors + the sub-DLA prior (multi :204-210)
+    delete b->mb;  // result tables are sized by nq: rebuilt by the next gpdla_batch_process_multi
+    b->mb = new MultiBuffers();
+    chk(upload(&b->mb->lp_dla, sp->log_priors_dla, nqs * md, st));
+    chk(upload(&b->mb->lp_lls, sp->log_priors_lls, nqs, st));
+  }
+  chk(put(b->d_meta, meta.data(), nqs * sizeof(QuasarMeta)));
+  chk(put(b->d_order, order.data(), nqs * 4));
   if (rc) return rc;
   if (hipStreamSynchronize(st) != hipSuccess) return fail(GPDLA_ERR_HIP, "upload synchronize failed");
   return GPDLA_OK;
@@ -731,8 +755,6 @@ int plan_records(gpdla_context *c, gpdla_batch *b, int64_t per_step, bool single
     b->plan_pool_records = most + kRecordPoolPad;
     b->plan_per_step = per_step;
     b->plan_budget = budget;
-    int rc = reserve(&b->d_rec_off, &b->cap.rec_off, (size_t)nq);
-    if (rc) return rc;
     // (h_rec_off lives as long as the batch: the copy may complete after this call returns)
     HIP_TRY(hipMemcpyAsync(b->d_rec_off, b->h_rec_off.data(), (size_t)nq * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
   }

@@ -32,8 +32,8 @@ from dataclasses import replace
 import numpy as np
 
 from . import _lib, io
-from .api import (Batch, Context, default_batch_size, dla_existence_prior, dla_existence_prior_multi,
-                  run_pipeline)
+from .api import (Batch, Context, batch_blocks, default_batch_size, dla_existence_prior,
+                  dla_existence_prior_multi, prefault, run_pipeline)
 from .distributed import (_world, gather_summaries, shard_bounds, summary_to_fields,
                           summary_to_fields_multi)
 from .parameters import MultiParameters, Parameters
@@ -108,7 +108,7 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
             if max_quasars_per_batch is None:
                 max_quasars_per_batch = default_batch_size(nloc, int(counts[lo:hi].max()), k, S, pipeline_slots,
                                                            multi_models=(p.max_dlas + 1) if multi else 0)
-            blocks = [(b, min(b + max_quasars_per_batch, nloc)) for b in range(0, nloc, max_quasars_per_batch)]
+            blocks = batch_blocks(nloc, max_quasars_per_batch)
             local = (Batch.empty_results_multi(nloc, p.max_dlas, S) if multi else Batch.empty_results(nloc, S))
             ctx = Context(device, p, stream=stream)
 
@@ -135,7 +135,8 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
             try:
                 ctx.set_model(model)
                 ctx.set_samples(samples)
-                run_pipeline(ctx, len(blocks), inputs, process, download, pipeline_slots)
+                run_pipeline(ctx, len(blocks), inputs, process, download, pipeline_slots,
+                             warm=lambda: prefault(local["sample_log_likelihoods_dla"]))
                 stream.synchronize()
             finally:
                 ctx.close()
