@@ -141,11 +141,14 @@ def cpu_baseline(model, samples, spectra, seconds_target=6.0, repeats=3):
     t_probe, _ = run(spectra[0], min(S, 8 * threads), threads)  # also warms the thread pool
     rate_guess = min(S, 8 * threads) / t_probe
     per_repeat = max(1, min(len(spectra), int(round(seconds_target * rate_guess / S))))
-    rates, spent_all = [], 0.0
+    rates, spent_all, checked = [], 0.0, {}
     for r in range(repeats):
         spent = 0.0
         for q in range(per_repeat):
-            spent += run(spectra[(r * per_repeat + q) % len(spectra)], S, threads)[0]
+            idx = (r * per_repeat + q) % len(spectra)
+            dt, res = run(spectra[idx], S, threads)
+            spent += dt
+            checked[idx] = res  # the oracle's numbers for this quasar: compared with the GPU's by main()
         rates.append(per_repeat * S / spent)
         spent_all += spent
     one_count = min(S, 256)
@@ -153,7 +156,7 @@ def cpu_baseline(model, samples, spectra, seconds_target=6.0, repeats=3):
     single = one_count / t1
     value = float(np.median(rates))
     n_desc = sorted({int(np.asarray(s["wavelengths"]).size) for s in spectra[:per_repeat * repeats]})
-    return dict(value=value, unit="evals/s", cores=int(threads), kind="port",
+    return checked, dict(value=value, unit="evals/s", cores=int(threads), kind="port",
                 cores_physical=info["cores_physical"], logical_cpus=info["logical_cpus"],
                 cpu_quota=info["cpu_quota"], cpu_model=info["cpu_model"], threads=int(threads),
                 repeats=repeats, rates=[float(x) for x in rates], single_core_value=single,
@@ -400,7 +403,24 @@ def main():
                                                       "results out; upload / sweep / download pipelined)")
             out["config"]["pcie_inclusive_over_resident"] = out["config"]["pcie_inclusive_evals_per_s"] / value
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, samples, spectra)
+            checked, out["cpu_baseline"] = cpu_baseline(model, samples, spectra)
+            # the quasars the oracle has just swept (all S samples each), against the timed GPU batch:
+            # the "max-abs delta" half of BASELINE.json's metric, measured on the bench workload itself
+            table, summ = batch.samples_tensor(), batch.summary_tensor()
+            worst = 0.0
+            for idx, ref in checked.items():
+                got = table[idx].cpu().numpy()
+                row = summ[idx].cpu().numpy()
+                worst = max(worst, float(np.nanmax(np.abs(got - ref["sample_log_likelihoods_dla"]))),
+                            abs(float(row[4]) - ref["log_likelihood_no_dla"]),
+                            abs(float(row[5]) - ref["log_likelihood_dla"]))
+            out["parity"] = {"max_abs_delta_vs_oracle": worst, "tolerance": 1e-8, "quasars": len(checked),
+                             "entries": len(checked) * (args.samples + 2),
+                             "what": "sample_log_likelihoods_dla, log_likelihoods_no_dla and log_likelihoods_dla of "
+                                     "the timed batch against the CPU oracle (the restatement of "
+                                     "process_qsos.m / log_mvnpdf_low_rank.m / voigt.c; no MATLAB exists here)"}
+            if args.contraction == "f64" and not (worst < 1e-8):
+                raise SystemExit(f"parity check failed: max |delta| vs the oracle = {worst}")
         print(json.dumps(out), flush=True)
     batch.close()
     ctx.close()
