@@ -467,14 +467,6 @@ int reserve(T **p, size_t *cap, size_t count) {
   return rc;
 }
 
-template <typename T>
-int reserve_copy(T **p, size_t *cap, const T *host, size_t count, hipStream_t st) {
-  int rc = reserve(p, cap, count);
-  if (rc) return rc;
-  if (count) HIP_TRY(hipMemcpyAsync(*p, host, count * sizeof(T), hipMemcpyHostToDevice, st));
-  return GPDLA_OK;
-}
-
 int validate_spectra(gpdla_context *c, const gpdla_spectra *sp, int *md_out) {
   if (!c->has_model || !c->has_samples)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "set the model and the samples before uploading spectra");

@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
   double xw[kXW] = {0.0, 0.0}, xu[kXU] = {0.0, 0.0, 0.0, 0.0};  // compact class: columns kept off the MFMA
   int dexp = 0;
   const int tile0 = role * NTW;
-  const int nw = TS == 1 ? TW : max(0, min(NTW, TW - tile0));  // w-tiles of this wave
+  [[maybe_unused]] const int nw = TS == 1 ? TW : max(0, min(NTW, TW - tile0));  // w-tiles of this wave (ablation build)
   const double tap0 = g_lines.taps[0], tap1 = g_lines.taps[1], tap2 = g_lines.taps[2],
                tap3 = g_lines.taps[3];
 

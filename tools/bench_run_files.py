@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""File-to-file rate of the sharded run on one GPU (world 1): -v7.3 inputs (cells deflate-compressed,
+as MATLAB writes them) -> gp_dla_detection_amd.run_dr12q.run -> the rank's chunk file.  Prints one
+JSON line with the phases."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from gp_dla_detection_amd import run_dr12q, synthetic  # noqa: E402
+
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+d = tempfile.mkdtemp(prefix="gpdla_files_")
+t0 = time.perf_counter()
+fs = synthetic.write_file_set(d, num_quasars=nq, num_samples=S, skip_every=10 ** 9, empty_quasar=None)
+t_gen = time.perf_counter() - t0
+pr = fs["prior"]
+run_dr12q.run(fs["paths"]["preloaded"], fs["paths"]["catalog"], fs["paths"]["learned"], fs["paths"]["samples"],
+              d + "/warm", "warm", test_ind=np.arange(64), prior_catalog=pr, device=0)  # warm-up
+t0 = time.perf_counter()
+res = run_dr12q.run(fs["paths"]["preloaded"], fs["paths"]["catalog"], fs["paths"]["learned"], fs["paths"]["samples"],
+                    d + "/out", "synth", prior_catalog=pr, device=0)
+t_run = time.perf_counter() - t0
+size = os.path.getsize(res["chunk"])
+print(json.dumps(dict(quasars=nq, samples=S, seconds=t_run, evals_per_s=nq * S / t_run, quasars_per_s=nq / t_run,
+                      chunk_bytes=size, input_bytes=os.path.getsize(fs["paths"]["preloaded"]),
+                      generate_inputs_s=t_gen, finite_p_dlas=int(np.isfinite(res["fields"]["p_dlas"]).sum()))))
