@@ -298,6 +298,13 @@ def main():
     batch = ctx.upload(spectra, lp[0], lp[1])  # inputs resident in HBM before the timed region
     ctx.set_timing(True)
     counts = [args.spectra] * world
+    if world > 1:
+        # set-up, like the upload above: the first collective creates the RCCL communicator (seconds);
+        # it must not fall into the timed region when the driver asks for --warmup 0
+        with torch.cuda.stream(stream):
+            probe = torch.zeros(8, dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local_rank}")
+            dist.all_reduce(probe)
+        torch.cuda.synchronize()
 
     def step():
         with torch.cuda.stream(stream):
