@@ -133,3 +133,10 @@ def run_files_rank(rank, world, port, multi, in_dir, out_dir, per_batch):
     finally:
         if world > 1:
             dist.destroy_process_group()
+
+
+def run_cli(argv):
+    """`python -m gp_dla_detection_amd.run_dr12q <argv>` in a clean child of the fork server."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from gp_dla_detection_amd import run_dr12q
+    run_dr12q.main(list(argv))

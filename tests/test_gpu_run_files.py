@@ -134,3 +134,27 @@ def test_committed_consumer_chunks_are_reproduced(tmp_path):
                 else:
                     np.testing.assert_allclose(np.asarray(va, dtype=np.float64), np.asarray(vb, dtype=np.float64),
                                                rtol=1e-9, atol=1e-9, err_msg=key)
+
+
+def test_command_line_entry_point(fileset, tmp_path):
+    """`python -m gp_dla_detection_amd.run_dr12q --preloaded ... --out ...` (world 1): the chunk it writes
+    is the unsharded run."""
+    fs = fileset
+    p = fs["paths"]
+    argv = ["--preloaded", p["preloaded"], "--catalog", p["catalog"], "--learned", p["learned"], "--samples",
+            p["samples"], "--prior", p["prior"], "--out", str(tmp_path), "--name", "cli", "--batch", "5"]
+    ctx = mp.get_context("forkserver")
+    pr = ctx.Process(target=sharded_worker.run_cli, args=(argv,))
+    pr.start()
+    pr.join(900)
+    if pr.is_alive():
+        pr.kill()
+        pr.join()
+    assert pr.exitcode == 0
+    ref, sel = reference_run(fs, False)
+    chunks = sorted(glob.glob(str(tmp_path / "processed_qsos_cli_[0-9]*.mat")))
+    assert len(chunks) == 1 and chunks[0].endswith(f"_000000-{sel.size:06d}.mat")
+    part = io.load_processed_qsos(chunks[0])
+    np.testing.assert_array_equal(part["sample_log_likelihoods_dla"], ref["sample_log_likelihoods_dla"])
+    np.testing.assert_array_equal(part["p_dlas"], ref["p_dlas"])
+    assert part["test_set_name"] == "cli"
