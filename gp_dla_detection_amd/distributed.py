@@ -163,41 +163,85 @@ def run_sharded(bounds, rank, ncol, sweep_block, group=None):
     return gather_summaries(table, counts, group), (lo, hi), local
 
 
-def process_qsos_sharded(model, samples, spectra, log_priors, params=None, device=None,
-                         pixel_counts=None):
-    """process_qsos over every quasar with the work split across the ranks of the default process
-    group.  ``spectra``: the full list (every rank passes the same one), or a loader
-    ``f(lo, hi) -> list`` together with ``pixel_counts`` so that a rank reads only its block.
-    ``log_priors = (no_dla, dla)`` for ALL quasars.  Returns (gathered summary fields for all
-    quasars, this rank's (lo, hi) block, this rank's sample_log_likelihoods_dla [hi-lo, S] or
-    None for an empty block)."""
+def sweep_block_pipelined(model, samples, block_spectra, priors, params, device, multi, first_index=0,
+                          base_sample_inds=None, max_quasars_per_batch=None, pipeline_slots=3):
+    """One rank's block of a sharded run, swept in bounded HBM-resident batches through
+    api.run_pipeline (upload i+1 / sweep i / download i-1).  Each batch's summary rows are copied,
+    behind its sweep on the same stream, into the rank's device table -- what the RCCL all-gather
+    then reads.  Returns (table [n, ncol] on the device, host results of the block)."""
     import torch
 
     from . import _lib
-    from .api import Context
+    from .api import Batch, Context, batch_blocks, default_batch_size, prefault, run_pipeline
+
+    n = len(block_spectra)
+    S = np.asarray(samples["offset_samples"]).size
+    k = np.asarray(model["M"]).shape[1]
+    md = params.max_dlas if multi else 0
+    ncol = _lib.summary_cols_multi(md) if multi else _lib.SUMMARY_COLS
+    stream = torch.cuda.Stream(device=device)
+    table = torch.empty((n, ncol), dtype=torch.float64, device=f"cuda:{device}")
+    if max_quasars_per_batch is None:
+        longest = max(np.asarray(s["wavelengths"]).size for s in block_spectra)
+        max_quasars_per_batch = default_batch_size(n, longest, k, S, pipeline_slots, multi_models=(md + 1) if multi else 0)
+    blocks = batch_blocks(n, max_quasars_per_batch)
+    local = Batch.empty_results_multi(n, md, S) if multi else Batch.empty_results(n, S)
+    ctx = Context(device, params, stream=stream)
+
+    def inputs(i):
+        b0, b1 = blocks[i]
+        return (block_spectra[b0:b1],) + tuple(np.asarray(p)[b0:b1] for p in priors)
+
+    def process(i, batch):
+        b0, b1 = blocks[i]
+        with torch.cuda.stream(stream):
+            if multi:
+                ctx.set_params(replace(params, first_quasar_index=first_index + b0))
+                batch.process_multi(None if base_sample_inds is None else np.asarray(base_sample_inds)[b0:b1])
+            else:
+                batch.process()
+            table[b0:b1].copy_(batch.summary_tensor())
+
+    def download(i, batch):
+        b0 = blocks[i][0]
+        (batch.download_multi(True, local, b0) if multi else batch.download(True, local, b0))
+
+    try:
+        ctx.set_model(model)
+        ctx.set_samples(samples)
+        run_pipeline(ctx, len(blocks), inputs, process, download, pipeline_slots,
+                     warm=lambda: prefault(local["sample_log_likelihoods_dla"]))
+        stream.synchronize()
+    finally:
+        ctx.close()
+    return table, local
+
+
+def process_qsos_sharded(model, samples, spectra, log_priors, params=None, device=None,
+                         pixel_counts=None, max_quasars_per_batch=None):
+    """process_qsos over every quasar with the work split across the ranks of the default process
+    group.  ``spectra``: the full list (every rank passes the same one), or a loader
+    ``f(lo, hi) -> list`` together with ``pixel_counts`` so that a rank reads only its block.
+    ``log_priors = (no_dla, dla)`` for ALL quasars.  A rank sweeps its block in bounded, pipelined
+    batches (:func:`sweep_block_pipelined`).  Returns (gathered summary fields for all quasars,
+    this rank's (lo, hi) block, this rank's sample_log_likelihoods_dla [hi-lo, S] or None for an
+    empty block)."""
+    import torch
+
+    from . import _lib
+    from .parameters import Parameters
 
     world, rank = _world()
     if device is None:
         device = torch.cuda.current_device()
+    p = params or Parameters()
     bounds = shard_bounds(_pixel_counts(spectra, pixel_counts), world)
     lp_no, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
 
     def sweep_block(lo, hi):
-        ctx = Context(device, params)
-        try:
-            ctx.set_model(model)
-            ctx.set_samples(samples)
-            batch = ctx.upload(_block(spectra, lo, hi), lp_no[lo:hi], lp_dla[lo:hi])
-            try:
-                batch.process()
-                ctx.synchronize()
-                table = batch.summary_tensor().clone()
-                local = batch.download()["sample_log_likelihoods_dla"]
-            finally:
-                batch.close()
-        finally:
-            ctx.close()
-        return table, local
+        table, local = sweep_block_pipelined(model, samples, _block(spectra, lo, hi), (lp_no[lo:hi], lp_dla[lo:hi]),
+                                             p, device, False, max_quasars_per_batch=max_quasars_per_batch)
+        return table, local["sample_log_likelihoods_dla"]
 
     table, block, local = run_sharded(bounds, rank, _lib.SUMMARY_COLS, sweep_block)
     return summary_to_fields(table), block, local
@@ -205,9 +249,9 @@ def process_qsos_sharded(model, samples, spectra, log_priors, params=None, devic
 
 def process_qsos_multiple_dlas_meanflux_sharded(model, samples, spectra, log_priors, params=None,
                                                 device=None, pixel_counts=None,
-                                                base_sample_inds=None):
+                                                base_sample_inds=None, max_quasars_per_batch=None):
     """The multi-DLA driver split across ranks.  ``log_priors = (no_dla [nq], lls [nq], dla [nq,
-    max_dlas])`` for ALL quasars.  Each rank's batch is told the global index of its first quasar
+    max_dlas])`` for ALL quasars.  Each rank's batches are told the global index of their first quasar
     (``first_quasar_index``), which keys the Philox stream of the weighted resampling (multi
     :467-472), so the indices drawn -- and with them every result -- equal those of an unsharded
     run.  ``base_sample_inds`` (optional, [nq, max_dlas-1, S] for ALL quasars) replays supplied
@@ -217,7 +261,6 @@ def process_qsos_multiple_dlas_meanflux_sharded(model, samples, spectra, log_pri
     import torch
 
     from . import _lib
-    from .api import Context
     from .parameters import MultiParameters
 
     p = params or MultiParameters()
@@ -229,25 +272,13 @@ def process_qsos_multiple_dlas_meanflux_sharded(model, samples, spectra, log_pri
     lp_dla = lp_dla.reshape(lp_no.size, p.max_dlas)
 
     def sweep_block(lo, hi):
-        ctx = Context(device, replace(p, first_quasar_index=p.first_quasar_index + lo))
-        try:
-            ctx.set_model(model)
-            ctx.set_samples(samples)
-            batch = ctx.upload(_block(spectra, lo, hi), lp_no[lo:hi], lp_dla[lo:hi],
-                               lp_lls[lo:hi])
-            try:
-                batch.process_multi(None if base_sample_inds is None else
-                                    np.asarray(base_sample_inds)[lo:hi])
-                ctx.synchronize()
-                table = batch.summary_tensor().clone()
-                res = batch.download_multi()
-                local = {key: res[key] for key in ("sample_log_likelihoods_dla",
-                                                   "sample_log_likelihoods_lls", "base_sample_inds")}
-            finally:
-                batch.close()
-        finally:
-            ctx.close()
-        return table, local
+        table, res = sweep_block_pipelined(
+            model, samples, _block(spectra, lo, hi), (lp_no[lo:hi], lp_dla[lo:hi], lp_lls[lo:hi]), p, device, True,
+            first_index=p.first_quasar_index + lo,
+            base_sample_inds=None if base_sample_inds is None else np.asarray(base_sample_inds)[lo:hi],
+            max_quasars_per_batch=max_quasars_per_batch)
+        return table, {key: res[key] for key in ("sample_log_likelihoods_dla", "sample_log_likelihoods_lls",
+                                                 "base_sample_inds")}
 
     table, block, local = run_sharded(bounds, rank, _lib.summary_cols_multi(p.max_dlas), sweep_block)
     return summary_to_fields_multi(table, p.max_dlas), block, local

@@ -54,11 +54,11 @@ def run_rank(rank, world, port, kind, out_dir, num_quasars):
 
         if kind == "single":
             fields, block, local = distributed.process_qsos_sharded(
-                model, samples, loader, lp, device=0, pixel_counts=counts)
+                model, samples, loader, lp, device=0, pixel_counts=counts, max_quasars_per_batch=2)
             local = {} if local is None else {"sample_log_likelihoods_dla": local}
         else:
             fields, block, local = distributed.process_qsos_multiple_dlas_meanflux_sharded(
-                model, samples, loader, lp, params=p, device=0, pixel_counts=counts)
+                model, samples, loader, lp, params=p, device=0, pixel_counts=counts, max_quasars_per_batch=2)
             local = local or {}
         assert loaded == ([block] if block[1] > block[0] else [])
         np.savez(os.path.join(out_dir, f"{kind}_w{world}_r{rank}.npz"), block=np.array(block),
