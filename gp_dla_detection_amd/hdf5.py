@@ -566,9 +566,13 @@ class Dataset(_Node):
             a = np.frombuffer(self.file._mm, dtype=dt, count=count, offset=self.file._abs(where)).reshape(shape)
             return a if memmap else a.copy()
         ndims = len(shape)
-        out = np.zeros(shape, dtype=dt)
         chunks: list = []
         self._chunks(where, ndims, chunks)
+        if len(chunks) == 1 and tuple(cdims) == tuple(shape) and not any(chunks[0][0]):
+            # one chunk holding the whole dataset (every cell of a preloaded_qsos.mat): no staging copy
+            raw = self._decode_chunk(self.file._bytes(chunks[0][3], chunks[0][1]), chunks[0][2])
+            return np.frombuffer(raw, dtype=dt, count=count).reshape(shape)
+        out = np.zeros(shape, dtype=dt)
         for offs, csize, cmask, caddr in chunks:
             raw = self._decode_chunk(self.file._bytes(caddr, csize), cmask)
             block = np.frombuffer(raw, dtype=dt, count=int(np.prod(cdims))).reshape(cdims)

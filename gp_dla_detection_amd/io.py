@@ -303,14 +303,20 @@ class PreloadedReader:
         z = _vec(z_qsos)
         if z.size != self.num_quasars:
             raise ValueError(f"{self.num_quasars} spectra but {z.size} redshifts")
-        out = []
-        for i in np.asarray(indices):
-            cell = {k: _from_dataset(self._f, self._f.dereference(self._refs[k][i])) for k in self.KEYS}
-            out.append(dict(wavelengths=_vec(cell["all_wavelengths"]), flux=_vec(cell["all_flux"]),
-                            noise_variance=_vec(cell["all_noise_variance"]),
-                            pixel_mask=np.asarray(cell["all_pixel_mask"]).reshape(-1).astype(np.uint8),
-                            z_qso=float(z[i])))
-        return out
+        f, refs = self._f, self._refs
+
+        def vec(key, i, dt):
+            # the cells are plain numeric / logical vectors: their class attributes are not needed,
+            # only an empty cell (stored as its dimensions, MATLAB_empty) must be told apart
+            ds = f.dereference(refs[key][i])
+            if len(ds.shape) == 1 and "MATLAB_empty" in ds.attrs:
+                return np.zeros(0, dtype=dt)
+            return np.asarray(ds.read(), dtype=dt).reshape(-1)
+
+        return [dict(wavelengths=vec("all_wavelengths", i, np.float64), flux=vec("all_flux", i, np.float64),
+                     noise_variance=vec("all_noise_variance", i, np.float64),
+                     pixel_mask=vec("all_pixel_mask", i, np.uint8), z_qso=float(z[i]))
+                for i in np.asarray(indices)]
 
     def close(self):
         self._f.close()
