@@ -1095,6 +1095,32 @@ int launch_sweep_multi(gpdla_context *c, gpdla_batch *b, const SweepMultiArgs &a
   }
 }
 
+template <int ND>
+int launch_sweep_multi_split_nd(gpdla_context *c, SweepMultiArgs args) {
+  using ES = EpilogueShape<52, 4>;
+  const size_t lds = std::max(sweep_multi_split_lds_doubles(), (size_t)2 * ES::SPP * ES::stride(56)) * sizeof(double);
+  if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "multi split sweep needs %zu B of LDS", lds);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_multi_split<ND>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.blocks_per_quasar = (int32_t)((args.S + 1 + 2 * kSamplesPerWave - 1) / (2 * kSamplesPerWave));
+  const int64_t nblocks = 8 * (((int64_t)args.nq_sub + 7) / 8) * (int64_t)args.blocks_per_quasar;
+  if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "sub-batch too large for one launch");
+  hipLaunchKernelGGL(k_sweep_multi_split<ND>, dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  HIP_TRY(hipGetLastError());
+  return GPDLA_OK;
+}
+
+// 20 < k <= 40: the roles of a sample group share the gathers and weights (k_sweep_multi_split)
+int launch_sweep_multi_split(gpdla_context *c, const SweepMultiArgs &args) {
+  switch (args.mode == 0 ? 1 : args.mode) {
+    case 1: return launch_sweep_multi_split_nd<1>(c, args);
+    case 2: return launch_sweep_multi_split_nd<2>(c, args);
+    case 3: return launch_sweep_multi_split_nd<3>(c, args);
+    case 4: return launch_sweep_multi_split_nd<4>(c, args);
+    default: return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d > 4", args.mode);
+  }
+}
+
 // Result tables of a multi-DLA batch, allocated on first use.
 int multi_alloc(gpdla_batch *b) {
   MultiBuffers &mb = *b->mb;
@@ -1221,7 +1247,12 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
         sa.sample_ll_dla = mb.sll_dla;
         sa.sample_ll_lls = mb.sll_lls;
         sa.ll_no_dla = mb.ll_no;
-        rc = b->k <= 20 ? launch_sweep_multi<14, 1, 8, 13>(c, b, sa) : launch_sweep_multi<14, 4, 1, 52>(c, b, sa);
+        // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k <= 40 form in which every wave of a group gathers and
+        // weighs for itself, for A/B timing against k_sweep_multi_split
+        static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
+        sa.pix = b->d_pix;
+        rc = b->k <= 20 ? launch_sweep_multi<14, 1, 8, 13>(c, b, sa)
+                        : legacy ? launch_sweep_multi<14, 4, 1, 52>(c, b, sa) : launch_sweep_multi_split(c, sa);
         if (rc) return rc;
       }
       // evidence, MAP, early-exit flags for the quasars of this sub-batch

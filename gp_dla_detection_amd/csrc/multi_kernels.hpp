@@ -158,6 +158,7 @@ struct SweepMultiArgs {
   const QuasarMeta *meta;
   const double *records;
   const double *prof;
+  const PixelRow *pix;         // per-pixel pool (k_sweep_multi_split reads rows directly)
   const uint32_t *base_inds;   // [nq][max_dlas-1][S], 1-based (multi :116, :476)
   const int32_t *alive;        // [nq] 0 once an evidence came out NaN (multi :460-464)
   int64_t S, q0, stride;
@@ -358,6 +359,227 @@ __global__ __launch_bounds__(512) void k_sweep_multi(SweepMultiArgs a) {
     const int64_t slot_s = slot0 + sigma;
     const bool ok_s = __shfl(chain_ok, sigma) != 0;  // lane sigma (jj = 0) holds sample sigma's flag
     if (writer) {
+      if (slot_s < a.S) {
+        if (a.mode == 0) a.sample_ll_lls[q * a.S + slot_s] = ll + m.ll_bias - a.log_S;     // multi :376-378
+        else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ok_s ? ll + m.ll_bias - a.log_S : NAN;  // :359-361
+      } else if (slot_s == a.S && a.mode == 1) {
+        a.ll_no_dla[q] = ll + m.ll_bias;                                                    // multi :296-298
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep_multi_split: k_sweep_multi for 20 < k <= 40 with the k_sweep_split pipeline
+// (sweep_split_kernel.hpp).  56 accumulator tiles do not fit one wave, so four waves ("roles") share
+// a group of 16 samples and take 14 tiles each.  In k_sweep_multi<14, 4, ...> every one of the four
+// gathered the group's profile values and formed the weights itself -- the HBM gathers of the
+// profile table four times over -- and the block met at a barrier every K-step.  Here role r
+// gathers and weighs only the K-steps t = r (mod 4), into a double-buffered (w, u) table in LDS,
+// and every role reads (w, u) of each K-step for its 14 MFMAs; one loop iteration is 4 K-steps (two
+// 2-step record chunks).  The profile values of step 4 (it + 2) + r are requested at the top of
+// iteration it and multiplied at the end of iteration it + 1: two iterations (8 K-steps) of latency
+// hiding for the HBM gather.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr size_t sweep_multi_split_lds_doubles() {
+  constexpr int RD = 56 * 64 + record_extras(56);
+  return 2 * 2 * (size_t)RD + 2 * 2 * 2 * 4 * 64 + 2 * 4 * 2 * 16;  // stage | (w, u) | per-role partial sums
+}
+
+template <int ND>
+__global__ __launch_bounds__(512) void k_sweep_multi_split(SweepMultiArgs a) {
+  extern __shared__ double smem[];
+  constexpr int WAVES = 8, TS = 4, NTW = 14, NT = 56, TW = 52, CH = 2;
+  constexpr int RD = NT * 64 + record_extras(NT);
+  const int64_t xj = blockIdx.x >> 3;
+  const int64_t ql = 8 * (xj / a.blocks_per_quasar) + (blockIdx.x & 7);
+  const int bq = (int)(xj % a.blocks_per_quasar);
+  if (ql >= a.nq_sub) return;
+  const int64_t q = a.q0 + ql;
+  const QuasarMeta m = a.meta[q];
+  if (m.status != 0 || a.alive[q] == 0) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int group = wave >> 2, role = wave & 3;
+  const int s = lane & 15, jj = lane >> 4;
+
+  double *stage = smem;                                    // [2][CH][RD]
+  double *wu = stage + (size_t)2 * CH * RD;                // [2 parity][2 groups][2][4 steps][64]
+  double *red = wu + 2 * 2 * 2 * 4 * 64;                   // [2 groups][4 roles][2][16]
+
+  const int64_t slot0 = (int64_t)bq * (2 * kSamplesPerWave) + group * kSamplesPerWave;
+  const int64_t slot = slot0 + s;
+  const bool is_sample = slot < a.S;
+  const bool is_null = !is_sample;
+  const int64_t i = is_sample ? slot : 0;
+  // rows of the profile table this lane multiplies (multi :342-351); see k_sweep_multi
+  const double *rows[4];
+  rows[0] = a.prof + ((ql * 2 + (a.mode == 0 ? 1 : 0)) * a.S + i) * a.stride;
+  int chain_ok = 1;
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    int64_t kk = i;
+    if (j < ND) {
+      kk = (int64_t)a.base_inds[((int64_t)q * (a.max_dlas - 1) + (j - 1)) * a.S + i] - 1;
+      if (kk < 0 || kk >= a.S) {
+        chain_ok = 0;
+        kk = i;
+      }
+    }
+    rows[j] = a.prof + ((ql * 2) * a.S + kk) * a.stride;
+  }
+  const PixelRow *pix = a.pix + m.pix_off;
+  const double *rec_base = a.records + m.rec_off * (int64_t)RD;
+  const int nchunks = (m.steps + CH - 1) / CH;
+  const int niter = (m.steps + 3) / 4;
+  static_assert((CH * RD) % 128 == 0, "a chunk is a whole number of KiB");
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t stage_lds = __builtin_amdgcn_readfirstlane(lds_address(stage));
+  auto issue_chunk = [&](int c) {
+    glds_chunk<CH * RD / 128, WAVES>(rec_base + (size_t)c * CH * RD, stage_lds + (uint32_t)(c & 1) * (uint32_t)(CH * RD * 8),
+                                     wave_s, lane);
+  };
+  issue_chunk(0);
+
+  const int p_last = 4 * m.steps + jj;  // rows are padded to 4 (steps + 1) entries
+  auto gather = [&](int t, double (&r)[ND]) {
+    const int p = min(4 * t + jj, p_last);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) r[j] = rows[j][p];
+  };
+  auto pix_of = [&](int t) -> PixelRow { return pix[4 * min(t, m.steps) + jj]; };  // row `steps` is neutral
+  double quad_sum = 0.0, dprod = 1.0;
+  int dexp = 0;
+  auto weights_of = [&](int t, const PixelRow &px, const double (&r)[ND], double *w_out, double *u_out) {
+    double absorb = r[0];
+#pragma unroll
+    for (int j = 1; j < ND; ++j) absorb *= r[j];
+    if (is_null) absorb = 1.0;
+    const double rr = fma(-absorb, px.mu, px.y);   // multi :355
+    const double a2 = absorb * absorb;
+    const double d = fma(px.omega2, a2, px.nu);    // multi :357, :361
+    const double inv_d = fast_rcp(d);
+    *w_out = a2 * inv_d;
+    *u_out = absorb * rr * inv_d;
+    if (t < m.steps) {  // (steps beyond the last are never consumed; keep them out of the sums)
+      quad_sum = fma(rr * rr, inv_d, quad_sum);
+      dprod *= d;
+      dexp += __builtin_amdgcn_frexp_exp(dprod);
+      dprod = __builtin_amdgcn_frexp_mant(dprod);
+    }
+  };
+  auto wu_slot = [&](int par, int which, int step) -> double * {
+    return wu + ((((size_t)par * 2 + group) * 2 + which) * 4 + step) * 64 + lane;
+  };
+
+  // prime: (w, u) of K-steps 0..3 (role r: step r); profile values of step 4 + r in flight
+  double g_cur[ND], g_next[ND];
+  {
+    double g0[ND], w0, u0;
+    gather(role, g0);
+    gather(4 + role, g_cur);
+    weights_of(role, pix_of(role), g0, &w0, &u0);
+    *wu_slot(0, 0, role) = w0;
+    *wu_slot(0, 1, role) = u0;
+  }
+  d4 acc[NTW];
+#pragma unroll
+  for (int c = 0; c < NTW; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+  const int tile0 = role * NTW;
+  constexpr int kTail = NT - TW;  // the last role's last 4 tiles take u
+
+  glds_wait();  // chunk 0 landed
+  __syncthreads();
+
+  for (int it = 0; it < niter; ++it) {
+    const int par = it & 1;
+    const int t_w = 4 * (it + 1) + role;
+    PixelRow px_w;
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {
+      const int c = 2 * it + hc;
+      if (c < nchunks) {  // block-uniform
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // (see k_sweep: free here, keeps compiler waits out of the K-steps)
+        if (c + 1 < nchunks) issue_chunk(c + 1);
+        if (hc == 0) {
+          px_w = pix_of(t_w);
+          gather(t_w + 4, g_next);  // for the W stage of the NEXT iteration
+        }
+        const double *buf = stage + (size_t)hc * CH * RD;  // chunk c lives in buffer c & 1 = hc
+#pragma unroll
+        for (int tt = 0; tt < CH; ++tt) {
+          const int rn = c * CH + tt;
+          if (rn < m.steps) {
+            const int st = 2 * hc + tt;  // step within the iteration
+            const double w = *wu_slot(par, 0, st), u = *wu_slot(par, 1, st);
+            const double *bt = buf + (size_t)tt * RD + (size_t)tile0 * 64 + lane;
+            double bop[NTW];
+#pragma unroll
+            for (int cc = 0; cc < NTW; ++cc) bop[cc] = bt[(size_t)cc * 64];
+            const double a_tail = role == TS - 1 ? u : w;
+#pragma unroll
+            for (int cc = 0; cc < NTW; ++cc)
+              acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < NTW - kTail ? w : a_tail, bop[cc], acc[cc], 0, 0, 0);
+          }
+        }
+        if (hc == 1) {  // stage W of this role for the next iteration
+          double w1, u1;
+          weights_of(t_w, px_w, g_cur, &w1, &u1);
+          *wu_slot(par ^ 1, 0, role) = w1;
+          *wu_slot(par ^ 1, 1, role) = u1;
+#pragma unroll
+          for (int j = 0; j < ND; ++j) g_cur[j] = g_next[j];
+        }
+        glds_wait();
+        __syncthreads();
+      } else if (hc == 1) {
+        __syncthreads();  // odd number of chunks: keep the barrier structure uniform
+      }
+    }
+  }
+
+  double logd_sum = log(dprod) + (double)dexp * 0.6931471805599453;
+  quad_sum += __shfl_xor(quad_sum, 16);
+  quad_sum += __shfl_xor(quad_sum, 32);
+  logd_sum += __shfl_xor(logd_sum, 16);
+  logd_sum += __shfl_xor(logd_sum, 32);
+  if (jj == 0) {
+    red[((group * 4 + role) * 2 + 0) * 16 + s] = quad_sum;
+    red[((group * 4 + role) * 2 + 1) * 16 + s] = logd_sum;
+  }
+  __syncthreads();
+  quad_sum = 0.0;
+  logd_sum = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    quad_sum += red[((group * 4 + r) * 2 + 0) * 16 + s];
+    logd_sum += red[((group * 4 + r) * 2 + 1) * 16 + s];
+  }
+  __syncthreads();
+
+  // epilogue: all four roles factor, 32 lanes per sample (as k_sweep_split)
+  using ES = EpilogueShape<TW, TS>;
+  constexpr int ncols = ES::stride(logical_tiles(NT));
+  constexpr int voff = TW * 16;
+  double *Eg = stage + (size_t)group * ES::SPP * ncols;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    __syncthreads();
+    double *e = Eg + (size_t)(jj * 2) * ncols;
+#pragma unroll
+    for (int cc = 0; cc < NTW; ++cc) {
+      const int tile = tile0 + cc;
+      const int col0 = tile < TW ? tile * 16 : voff + (tile - TW) * 16;
+      e[col0 + s] = acc[cc][2 * p];
+      e[ncols + col0 + s] = acc[cc][2 * p + 1];
+    }
+    __syncthreads();
+    const int rho = 2 * role + (lane >> 5);
+    const int sigma = (rho >> 1) + 4 * (2 * p + (rho & 1));  // Mat<double>::sample_of(jj, reg)
+    const double q_s = __shfl(quad_sum, sigma), ld_s = __shfl(logd_sum, sigma);
+    const bool ok_s = __shfl(chain_ok, sigma) != 0;
+    const double ll = factor_lds<2, 32>(Eg + (size_t)rho * ncols, lane & 31, a.k, voff, q_s, ld_s, m.n_kept);
+    const int64_t slot_s = slot0 + sigma;
+    if ((lane & 31) == 0) {
       if (slot_s < a.S) {
         if (a.mode == 0) a.sample_ll_lls[q * a.S + slot_s] = ll + m.ll_bias - a.log_S;     // multi :376-378
         else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ok_s ? ll + m.ll_bias - a.log_S : NAN;  // :359-361
