@@ -113,6 +113,14 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
   // window of raw values P .. P+6 for output pixel P (the profile of pixel p uses padded p .. p+6)
   double r0 = raw_at(0), r1 = raw_at(1), r2 = raw_at(2), r3 = raw_at(3), r4 = raw_at(4), r5 = raw_at(5), r6;
   const int64_t nrows = min((int64_t)64, a.S - pos0);
+  // the 16 profile rows this lane stores into (store instruction e writes rows 4e .. 4e+3): their
+  // offsets once, not a perm look-up and a 64-bit multiply per store
+  int64_t roff[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int rl = 4 * e + (lane >> 4);
+    roff[e] = rl < nrows ? (int64_t)a.perm[pos0 + rl] * a.stride + (lane & 15) : -1;
+  }
   for (int p0 = 0; p0 < m.n_u; p0 += kProfTile) {
 #pragma unroll
     for (int tt = 0; tt < kProfTile; ++tt) {
@@ -131,13 +139,11 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
     __builtin_amdgcn_wave_barrier();
     // transposed store: instruction e writes pixels p0 .. p0+15 of rows 4e .. 4e+3
     const int tt = lane & 15;
-#pragma unroll 4
+    const bool in_row = p0 + tt < m.n_u;
+#pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int rl = 4 * e + (lane >> 4);
-      if (rl < nrows && p0 + tt < m.n_u) {
-        const int64_t ir = a.perm[pos0 + rl];
-        rows[ir * a.stride + p0 + tt] = s_out[wave][rl][tt];
-      }
+      if (roff[e] >= 0 && in_row) rows[roff[e] + p0] = s_out[wave][rl][tt];
     }
     __builtin_amdgcn_wave_barrier();
   }
