@@ -728,6 +728,10 @@ int plan_records(gpdla_context *c, gpdla_batch *b, int64_t per_step, bool single
   const int64_t budget = single_group ? INT64_MAX : std::max<int64_t>(1, budget_bytes / (per_step * 8));
   if (b->plan_per_step != per_step || b->plan_budget != budget) {
     const int64_t nq = b->nq;
+    // h_rec_off is the source of an asynchronous copy enqueued by the previous plan, in front of
+    // that process call's kernels: it may be rewritten once they have run (a no-op after a reload,
+    // which has waited for the same event)
+    HIP_TRY(hipEventSynchronize(b->ev_done));
     b->h_rec_off.assign((size_t)nq, 0);
     b->groups.clear();
     int64_t cur = 0, g0 = 0, most = 0;
