@@ -8,7 +8,7 @@ SRC=gp_dla_detection_amd/csrc/gpdla.hip
 FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -Wno-inline-asm"
 mkdir -p gpurun_out /tmp/ablate
 hipcc $FLAGS -DGPDLA_STAMP $SRC -o /tmp/ablate/lib_stamp.so
-GPDLA_LIB_PATH=/tmp/ablate/lib_stamp.so python3 - "$@" <<'PY' | tee gpurun_out/stamps.txt
+GPDLA_EXPANDED_RECORDS=1 GPDLA_LIB_PATH=/tmp/ablate/lib_stamp.so python3 - "$@" <<'PY' | tee gpurun_out/stamps.txt
 import ctypes, json, subprocess, sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
