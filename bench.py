@@ -374,7 +374,10 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, "
                          f"profiles/pmc_latest.json{', tag ' + traffic_tag if traffic_tag else ''}; null unless "
-                         "measured on this libgpdla.so and workload)", "kernel": "k_sweep",
+                         "measured on this libgpdla.so and workload)",
+                         "kernel": ("k_sweep_slim" if args.k <= 20 and args.contraction == "f64"
+                                    and not os.environ.get("GPDLA_EXPANDED_RECORDS") else
+                                    "k_sweep_split" if args.k > 20 and args.contraction == "f64" else "k_sweep"),
                          "kernel_ms": sweep_ms,
                          "flops_per_launch": flops,
                          "flops_per_eval": algorithmic_flops(float(n_kept.mean()), args.k)},
