@@ -316,6 +316,16 @@ class Batch:
         out["log_priors_dla"][at:at + nq] = self.log_priors_dla
         return out
 
+    def debug_prepared_rows(self, quasar: int = 0, multi: bool = False) -> np.ndarray:
+        """Test hook (gpdla_debug_prepared_rows): the (y, mu, omega2, nu) rows of one quasar on the
+        unmasked-range grid after the preparation kernel alone, [n_u, 4]."""
+        cap = 8192
+        rows = np.empty((cap, 4))
+        n = C.c_int64()
+        _lib.check(self.ctx.lib.gpdla_debug_prepared_rows(self.ctx._h, self._h, int(bool(multi)), int(quasar),
+                                                          rows.ctypes.data_as(_dp), cap, C.byref(n)))
+        return rows[: n.value].copy()
+
     def summary_tensor(self):
         """The per-quasar summary table as a zero-copy torch tensor on this GPU: [nq, 15] for a
         single-DLA batch, [nq, GPDLA_SUMMARY_COLS_MULTI(max_dlas)] (78 for max_dlas = 4) for a

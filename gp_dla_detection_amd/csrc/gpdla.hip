@@ -1827,6 +1827,29 @@ extern "C" int gpdla_debug_near_poly(int line, double x, double *value_out, doub
   return GPDLA_OK;
 }
 
+// Test hook (gpdla.h): k_prepare alone, then the rows of one quasar.
+extern "C" int gpdla_debug_prepared_rows(gpdla_context *c, gpdla_batch *b, int multi, int64_t quasar,
+                                         double *rows_out, int64_t capacity_rows, int64_t *num_rows_out) {
+  if (!c || !b || b->ctx != c || !rows_out || !num_rows_out)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched argument");
+  if (quasar < 0 || quasar >= b->nq) return fail(GPDLA_ERR_INVALID_ARGUMENT, "quasar %lld outside the batch", (long long)quasar);
+  HIP_TRY(hipSetDevice(c->device_id));
+  int rc = plan_records(c, b, b->k <= 20 ? kSlimRec : record_doubles(b->ntiles, 0), true);
+  if (rc) return rc;
+  if ((rc = launch_prepare(c, b, multi != 0))) return rc;
+  QuasarMeta m;
+  HIP_TRY(hipMemcpyAsync(&m, b->d_meta + quasar, sizeof(m), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int64_t n = std::min<int64_t>(m.n_u, capacity_rows);
+  static_assert(sizeof(PixelRow) == 4 * sizeof(double), "rows_out is [n][4] doubles");
+  if (n > 0) {
+    HIP_TRY(hipMemcpyAsync(rows_out, b->d_pix + m.pix_off, (size_t)n * sizeof(PixelRow), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  *num_rows_out = n;
+  return GPDLA_OK;
+}
+
 #ifdef GPDLA_STAMP
 // Diagnostic build only (tools/stamps.sh): read and clear the per-segment wave-cycle sums.
 extern "C" int gpdla_debug_stamps(unsigned long long *out) {

@@ -312,6 +312,15 @@ void gpdla_training_destroy(gpdla_training *t);
  * ------------------------------------------------------------------------------------------- */
 int gpdla_debug_near_poly(int line, double x, double *value_out, double *y_out);
 
+/* Test hook: runs only the preparation kernel of a batch (pixel selection, GP interpolation, noise
+ * scaling; with multi != 0 the Lyman-series scaling and mean-flux suppression of
+ * process_qsos_multiple_dlas_meanflux.m:245-293) and copies out, for quasar `quasar`, its rows on
+ * the unmasked-range grid: rows_out[4 i + (0..3)] = (y, mu, omega2, nu) of pixel i (masked pixels:
+ * 0, 0, 0, 1), for i < *num_rows_out <= capacity_rows.  Lets a test hold the GPU's mean-flux factor
+ * to the numbers the reference's own QSOLoader.total_scale_factor produced (tests/golden/mean_flux.npz). */
+int gpdla_debug_prepared_rows(gpdla_context *ctx, gpdla_batch *batch, int multi, int64_t quasar,
+                              double *rows_out, int64_t capacity_rows, int64_t *num_rows_out);
+
 /* The counter-based generator behind the multi-DLA resampling (Philox4x32-10 of Salmon et al.,
  * SC'11), evaluated on the HOST by the same function the kernel compiles: out = philox(ctr, key).
  * For known-answer tests against the Random123 vectors.  Needs no GPU. */

@@ -485,6 +485,27 @@ int gpdla_oracle_process_spectrum(const gpdla_oracle_params *prm, const gpdla_or
   return 0;
 }
 
+/* Mean-flux suppression of one observed pixel, multi :267-285: exp(-Sum_l tau_l (1 + z_l)^beta) over the
+ * first num_forest_lines Lyman lines, tau_l = prev_tau_0 f_l / f_Lya lambda_l / lambda_Lya (:269-273),
+ * z_l = (lambda - lambda_l) / lambda_l (:184-186), lines other than Lyman-alpha counted only where
+ * z_l <= z_qso (:279-282; nansum skips the NaN-flagged entries).  The reference has its own Python
+ * restatement of exactly this, QSOLoader.total_scale_factor (CDDF_analysis/qso_loader.py:1777-1822):
+ * tests/golden/mean_flux.npz holds its output and pins this function. */
+double gpdla_oracle_mean_flux_suppression(double wavelength, double z_qso, double lya_wavelength,
+                                          double prev_tau_0, double prev_beta, int num_forest_lines) {
+  const double lya_f = oscillator_strengths[0]; /* lya_oscillator_strength, set_parameters_multi.m */
+  double total = 0.0;
+  for (int l = 0; l < num_forest_lines; l++) {
+    double wl_l = transition_wavelengths[l] * 1e8;
+    double z_l = (wavelength - wl_l) / wl_l;                              /* multi :184-186 */
+    double this_tau_0 = prev_tau_0 * oscillator_strengths[l] / lya_f * wl_l / lya_wavelength;
+    double od = this_tau_0 * pow(1 + z_l, prev_beta);                     /* multi :275-276 */
+    if (l > 0 && z_l > z_qso) continue;                                   /* multi :279-282 */
+    total += od;
+  }
+  return exp(-total);                                                     /* multi :285 */
+}
+
 /* ------------------------------------------------------------------------------------------
  * multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-477 for one quasar ("multi :N" below).
  * ------------------------------------------------------------------------------------------ */
@@ -540,17 +561,9 @@ int gpdla_oracle_process_spectrum_multi(
     }
     double scaling = 1 - exp(-lya_optical_depth) + c_0;                   /* multi :261 */
     omega2 = omega2 * (scaling * scaling);                                /* multi :263 */
-    /* mean-flux suppression, multi :267-285 (nansum skips the NaN-flagged lines) */
-    double total = 0.0;
-    for (int l = 0; l < L; l++) {
-      double wl_l = transition_wavelengths[l] * 1e8;
-      double z_l = (s.wavelengths[i] - wl_l) / wl_l;                      /* multi :184-186 */
-      double this_tau_0 = mul->prev_tau_0 * oscillator_strengths[l] / lya_f * wl_l / prm->lya_wavelength;
-      double od = this_tau_0 * pow(1 + z_l, mul->prev_beta);              /* multi :275-276 */
-      if (l > 0 && z_l > z_qso) continue;                                 /* multi :279-282 */
-      total += od;
-    }
-    double lya_absorption = exp(-total);                                  /* multi :285 */
+    /* mean-flux suppression, multi :267-285 */
+    double lya_absorption = gpdla_oracle_mean_flux_suppression(s.wavelengths[i], z_qso, prm->lya_wavelength,
+                                                               mul->prev_tau_0, mul->prev_beta, L);
     this_mu[i] = mu_i * lya_absorption;                                   /* multi :287 */
     for (int c = 0; c < k; c++)
       this_M[i + c * n] = lerp(mdl->M + (size_t)c * G, i0, t) * lya_absorption; /* multi :229,:288 */

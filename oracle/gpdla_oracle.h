@@ -119,6 +119,11 @@ typedef struct {
   const double *log_nhi_samples;   /* [S] for MAP bookkeeping :389,:445 */
 } gpdla_oracle_multi;
 
+/* Mean-flux suppression factor of one observed pixel (multi :267-285); pinned by the reference's own
+ * QSOLoader.total_scale_factor through tests/golden/mean_flux.npz. */
+double gpdla_oracle_mean_flux_suppression(double wavelength, double z_qso, double lya_wavelength,
+                                          double prev_tau_0, double prev_beta, int num_forest_lines);
+
 /* multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-477 for one quasar.
  * sample_log_likelihoods_dla is [S x max_dlas] column-major (this_sample_log_likelihoods_dla, :146),
  * log_likelihoods_dla [max_dlas], sample_log_likelihoods_lls [S], MAP_* [max_dlas x max_dlas]

@@ -80,6 +80,9 @@ def _bind(lib):
     lib.gpdla_oracle_process_spectrum_multi.argtypes = [
         C.POINTER(_Params), C.POINTER(_Model), C.POINTER(_Multi), C.c_int64, _dp, _dp, C.c_int64,
         _dp, _dp, _dp, _u8p, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.gpdla_oracle_mean_flux_suppression.restype = C.c_double
+    lib.gpdla_oracle_mean_flux_suppression.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                                       C.c_int]
     lib.gpdla_oracle_objective.restype = C.c_int
     lib.gpdla_oracle_objective.argtypes = [_dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _dp, C.c_int,
                                            _dp, _dp]
@@ -132,6 +135,16 @@ def voigt(lambdas, z, N, num_lines=31, raw=False):
     if rc:
         raise ValueError(f"oracle voigt rc={rc}")
     return out
+
+
+def mean_flux_suppression(wavelengths, z_qso, prev_tau_0=0.0023, prev_beta=3.65, num_forest_lines=31,
+                          lya_wavelength=1215.6701):
+    """exp(-Sum_l tau_l (1 + z_l)^beta) per observed pixel, multi :267-285 (the factor the multi-DLA
+    driver multiplies mu and M by)."""
+    lib = load()
+    return np.array([lib.gpdla_oracle_mean_flux_suppression(float(w), float(z_qso), float(lya_wavelength),
+                                                            float(prev_tau_0), float(prev_beta), int(num_forest_lines))
+                     for w in np.asarray(wavelengths, dtype=np.float64).reshape(-1)])
 
 
 def log_mvnpdf_low_rank(y, mu, M, d):

@@ -80,6 +80,9 @@ def dump_loader(q, multi):
                 concordance_z_dlas=q.dla_catalog.z_dlas, concordance_log_nhis=q.dla_catalog.log_nhis,
                 flux_3=q.find_this_flux(3), wavelengths_3=q.find_this_wavelengths(3),
                 noise_variance_3=q.find_this_noise_variance(3))
+    if not multi:  # the MAP sample of every quasar, found by the reference from the sample table (:303-373)
+        q.prepare_roman_map_vals(sample_file=q.sample_file)
+        keep.update(all_log_nhis=q.all_log_nhis, all_z_dlas=q.all_z_dlas)
     if multi:
         keep.update(map_log_nhis=q.map_log_nhis, map_z_dlas=q.map_z_dlas, all_log_nhis=q.all_log_nhis,
                     all_z_dlas=q.all_z_dlas)

@@ -129,6 +129,11 @@ def test_what_qsoloader_read(tmp_path, inputs, multi):
     num = idx - int(multi)
     num[num < 0] = 0
     np.testing.assert_array_equal(q["dla_map_num_dla"], num)
+    if not multi:
+        # prepare_roman_map_vals (:303-373): the reference's argmax over OUR sample table, against the
+        # MAP columns the evidence kernel found on the GPU (generate_ascii_catalog.m:73-80)
+        np.testing.assert_array_equal(q["all_log_nhis"], res["MAP_log_nhis"])
+        np.testing.assert_array_equal(q["all_z_dlas"], res["MAP_z_dlas"])
     if multi:
         np.testing.assert_array_equal(q["map_z_dlas"], res["MAP_z_dlas"])      # f['MAP_z_dlas'][()].T (:107-109)
         np.testing.assert_array_equal(q["map_log_nhis"], res["MAP_log_nhis"])

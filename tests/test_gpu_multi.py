@@ -162,3 +162,32 @@ def test_randomised_multi_shapes_vs_oracle(oracle):
         bsi = out["base_sample_inds"][0] if md > 1 else np.zeros((0, S), np.uint32)
         ref = oracle_multi(oracle, model, samples, sp, bsi, p)
         compare(out, 0, ref, p)
+
+
+def test_gpu_mean_flux_suppression_against_the_references_own_python(golden):
+    """The preparation kernel's mean-flux factor (multi :267-285), read back through the test hook
+    gpdla_debug_prepared_rows, against the numbers the reference's QSOLoader.total_scale_factor
+    produced (tests/golden/mean_flux.npz): with mu = 1 on the model grid the prepared mu row IS that
+    factor.  A reference-produced anchor that reaches the GPU path directly, not through the oracle."""
+    from gp_dla_detection_amd.parameters import MultiParameters
+    g = golden("mean_flux.npz")
+    model = synthetic.make_model(20)
+    model = dict(model, mu=np.ones_like(model["mu"]))
+    samples = synthetic.make_samples(16)
+    for i in range(int(g["num_cases"])):
+        rest, z = g[f"rest_{i}"], float(g[f"z_qso_{i}"])
+        wl = rest * (1 + z)
+        p = MultiParameters(max_dlas=2, prev_tau_0=float(g[f"tau_{i}"]), prev_beta=float(g[f"beta_{i}"]),
+                            num_forest_lines=int(g[f"lines_{i}"]))
+        sp = dict(wavelengths=wl, flux=np.ones_like(wl), noise_variance=np.full_like(wl, 0.01),
+                  pixel_mask=np.zeros(wl.size, dtype=np.uint8), z_qso=z)
+        ctx = gp.Context(0, p)
+        ctx.set_model(model)
+        ctx.set_samples(samples)
+        batch = ctx.upload([sp], np.zeros(1), np.zeros((1, 2)), np.zeros(1))
+        rows = batch.debug_prepared_rows(0, multi=True)
+        batch.close()
+        ctx.close()
+        inside = (wl / (1 + z) >= p.min_lambda) & (wl / (1 + z) <= p.max_lambda)   # process_qsos.m:104-105
+        assert rows.shape[0] == inside.sum() and rows.shape[0] > 300
+        assert np.abs(rows[:, 1] / g[f"scale_{i}"][inside] - 1).max() < 1e-13, i

@@ -197,3 +197,17 @@ def test_thread_count_does_not_change_results(oracle):
                                 sp["wavelengths"], sp["flux"], sp["noise_variance"],
                                 sp["pixel_mask"], sp["z_qso"], num_threads=4)
     np.testing.assert_array_equal(a["sample_log_likelihoods_dla"], b["sample_log_likelihoods_dla"])
+
+
+def test_mean_flux_suppression_against_the_references_own_python(oracle, golden):
+    """multi :267-285.  The reference restates this one piece of the MATLAB driver in Python
+    (QSOLoader.total_scale_factor, CDDF_analysis/qso_loader.py:1777-1822); tests/golden/make_mean_flux.py
+    ran it in the build container and stored what it computed: a reference-PRODUCED number for the
+    driver half of the path.  The oracle's restatement agrees to rounding."""
+    g = golden("mean_flux.npz")
+    for i in range(int(g["num_cases"])):
+        rest, z = g[f"rest_{i}"], float(g[f"z_qso_{i}"])
+        got = oracle.mean_flux_suppression(rest * (1 + z), z, float(g[f"tau_{i}"]), float(g[f"beta_{i}"]),
+                                           int(g[f"lines_{i}"]))
+        assert np.abs(got / g[f"scale_{i}"] - 1).max() < 5e-15, i
+        assert 0.2 < g[f"scale_{i}"].min() < g[f"scale_{i}"].max() <= 1.0
