@@ -1433,7 +1433,7 @@ void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uin
 
 struct gpdla_training {
   int device_id = 0;
-  int64_t nq = 0, G = 0;
+  int64_t nq = 0, G = 0, ld = 0;  // ld: row stride of the training arrays (G rounded up to 16)
   double *d_flux = nullptr, *d_lya = nullptr, *d_noise = nullptr, *d_loglya = nullptr;
   double *d_x = nullptr, *d_g = nullptr, *d_omega2 = nullptr, *d_f = nullptr;
   int32_t *d_flag = nullptr;
@@ -1447,13 +1447,12 @@ struct gpdla_training {
   int ws_class = 0;  // rank class the workspace was sized for (20 or 40)
   double *h_stage = nullptr;  // pinned host staging for x (in) and [g | f | flag] (out)
   int64_t stage_capacity = 0;
-  // one evaluation = H2D of x, nine kernels, D2H of [g | f | flag]: captured once per k into a
+  // one evaluation = H2D of x, six kernels, D2H of [g | f | flag]: captured once per k into a
   // hipGraph and replayed (no kernel argument changes between evaluations)
   hipStream_t stream = nullptr;
   hipGraphExec_t graph = nullptr;
   int graph_k = 0;
-  double *d_scal = nullptr;
-  double *d_wA = nullptr, *d_uA = nullptr, *d_wB = nullptr, *d_uB = nullptr, *d_part1 = nullptr;
+  double *d_wB = nullptr, *d_uB = nullptr, *d_part1 = nullptr;
   double *d_recM = nullptr, *d_recP = nullptr, *d_partB = nullptr, *d_recD = nullptr, *d_recE = nullptr;
   double *d_nlogp = nullptr, *d_partD = nullptr, *d_partcol = nullptr, *d_partsc = nullptr;
 };
@@ -1475,8 +1474,8 @@ void training_drop_graph(gpdla_training *t) {
 
 void training_free_workspace(gpdla_training *t) {
   training_drop_graph(t);
-  for (double **p : {&t->d_wA, &t->d_uA, &t->d_wB, &t->d_uB, &t->d_part1, &t->d_recM, &t->d_recP, &t->d_partB,
-                     &t->d_recD, &t->d_recE, &t->d_nlogp, &t->d_partD, &t->d_partcol, &t->d_partsc, &t->d_scal}) {
+  for (double **p : {&t->d_wB, &t->d_uB, &t->d_part1, &t->d_recM, &t->d_recP, &t->d_partB,
+                     &t->d_recD, &t->d_recE, &t->d_nlogp, &t->d_partD, &t->d_partcol, &t->d_partsc}) {
     dev_free(*p);
     *p = nullptr;
   }
@@ -1512,28 +1511,27 @@ int gpdla_training_create(int device_id, int64_t nq, int64_t G, const double *fl
   t->device_id = device_id;
   t->nq = nq;
   t->G = G;
-  // MATLAB column-major [nq x G] -> quasar-major [nq][G] (one block streams one quasar)
-  const size_t n = (size_t)nq * G;
+  // MATLAB column-major [nq x G] -> quasar-major [nq][ld], ld = G rounded up to 16 pixels: the rows
+  // start 128-byte aligned and end in missing pixels (NaN flux, 1 + z = 1, unit noise), so the
+  // matrix-core kernels read whole 16-pixel chunks without bounds checks
+  const int64_t ld = 16 * ((G + 15) / 16);
+  t->ld = ld;
+  const size_t n = (size_t)nq * ld;
   std::vector<double> tmp(n);
-  auto up = [&](const double *src, double **dst) -> int {
-    for (int64_t i = 0; i < nq; ++i)
-      for (int64_t p = 0; p < G; ++p) tmp[(size_t)i * G + p] = src[i + p * nq];
+  auto up = [&](const double *src, double **dst, double pad, bool take_log) -> int {
+    for (int64_t i = 0; i < nq; ++i) {
+      for (int64_t p = 0; p < G; ++p) tmp[(size_t)i * ld + p] = take_log ? std::log(src[i + p * nq]) : src[i + p * nq];
+      for (int64_t p = G; p < ld; ++p) tmp[(size_t)i * ld + p] = pad;
+    }
     int r = dev_alloc(dst, n);
     if (r) return r;
     HIP_TRY(hipMemcpy(*dst, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
     return GPDLA_OK;
   };
-  auto up_log = [&](const double *src, double **dst) -> int {  // log(1 + z): data, taken once
-    for (int64_t i = 0; i < nq; ++i)
-      for (int64_t p = 0; p < G; ++p) tmp[(size_t)i * G + p] = std::log(src[i + p * nq]);
-    int r = dev_alloc(dst, n);
-    if (r) return r;
-    HIP_TRY(hipMemcpy(*dst, tmp.data(), n * sizeof(double), hipMemcpyHostToDevice));
-    return GPDLA_OK;
-  };
-  if ((rc = up(flux, &t->d_flux)) || (rc = up(lya, &t->d_lya)) || (rc = up(noise, &t->d_noise)) ||
-      (rc = up_log(lya, &t->d_loglya)) ||
-      (rc = dev_alloc(&t->d_omega2, (size_t)G)) || (rc = dev_alloc(&t->d_f, 1)) ||
+  if ((rc = up(flux, &t->d_flux, std::nan(""), false)) || (rc = up(lya, &t->d_lya, 1.0, false)) ||
+      (rc = up(noise, &t->d_noise, 1.0, false)) ||
+      (rc = up(lya, &t->d_loglya, 0.0, true)) ||  // log(1 + z): data, taken once
+      (rc = dev_alloc(&t->d_omega2, (size_t)ld)) || (rc = dev_alloc(&t->d_f, 1)) ||
       (rc = dev_alloc(&t->d_flag, 1))) {
     gpdla_training_destroy(t);
     return rc;
@@ -1555,10 +1553,20 @@ TrainDims train_dims(const gpdla_training *t, int k) {
   d.PG = (t->G + 15) / 16;
   d.T = 4 * d.PG;
   d.TQ = 4 * d.NQ16;
-  d.PB = (16 * d.PG + 63) / 64;
+  d.ld = 16 * d.PG;
   d.H = 6;    // 79 row blocks x 6 = 474 blocks of 4 waves for 5000 quasars (two per CU)
   d.H2 = 24;  // 20 row blocks x 24 = 480
   d.GS = 24;  // 20 pixel blocks x 24 = 480 blocks of 4 waves (59 KiB of LDS each: two per CU)
+  // (diagnostic: GPDLA_TRAIN_SPLITS="H,H2,GS" overrides the three splits)
+  static const char *splits = std::getenv("GPDLA_TRAIN_SPLITS");
+  int h = 0, h2 = 0, gs = 0;
+  if (splits && std::sscanf(splits, "%d,%d,%d", &h, &h2, &gs) == 3 && h > 0 && h2 > 0 && gs > 0 && h <= 64 &&
+      h2 <= 256 && gs <= 256) {
+    d.H = h;
+    d.H2 = h2;
+    d.GS = gs;
+  }
+  d.H = (int32_t)std::max<int64_t>(d.H, (d.PG + kTrBuildMaxChunks - 1) / kTrBuildMaxChunks);  // a split's omega2 table fits its LDS
   return d;
 }
 
@@ -1571,47 +1579,30 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   const int64_t strideM = (d.T + kTrChunk) * kTrGroupD, strideD = (d.TQ + kTrChunk) * kTrGroupD;
   const int64_t G = t->G, nx = G * (k + 1) + 3;
   HIP_TRY(hipMemcpyAsync(t->d_x, t->h_stage, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(t->d_flag, 0, sizeof(int32_t), st));
-  TrainScalarsArgs sc;
-  sc.x = t->d_x;
-  sc.G = G;
-  sc.k = k;
-  sc.omega2 = t->d_omega2;
-  sc.scal = t->d_scal;
-  hipLaunchKernelGGL(k_train_scalars, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, sc);
-  TrainPrepareArgs pa;
-  pa.d = d;
-  pa.flux = t->d_flux;
-  pa.log_lya_1pz = t->d_loglya;
-  pa.noise = t->d_noise;
-  pa.omega2 = t->d_omega2;
-  pa.scal = t->d_scal;
-  pa.wA = t->d_wA;
-  pa.uA = t->d_uA;
-  pa.wB = t->d_wB;
-  pa.uB = t->d_uB;
-  pa.part1 = t->d_part1;
-  hipLaunchKernelGGL(k_train_prepare, dim3((unsigned)(d.NQ16 * d.PB)), dim3(256), 0, st, pa);
   TrainRecordsArgs ra;
   ra.d = d;
   ra.M = t->d_x;
   ra.recM = t->d_recM;
   ra.recP = t->d_recP;
   ra.group_stride = strideM;
+  ra.not_pd = t->d_flag;
+  ra.omega2 = t->d_omega2;
   hipLaunchKernelGGL(k_train_records<KMAX>, dim3(1024), dim3(256), 0, st, ra);
-  TrainContractArgs ca;  // B_q, t_q: rows = quasars, steps over pixels
-  ca.Aw = t->d_wA;
-  ca.Au = t->d_uA;
-  ca.Brec = t->d_recM;
-  ca.R = d.NQ16;
-  ca.steps = d.T;
-  ca.nsplit = d.H;
-  ca.groups = K::Groups;
-  ca.w_tiles = K::W;
-  ca.cols = K::Cols;
-  ca.group_stride = strideM;
-  ca.out = t->d_partB;
-  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H * K::Groups)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
+  TrainBuildArgs ba;  // B_q, t_q: rows = quasars, steps over pixels, w and u made on the fly
+  ba.d = d;
+  ba.flux = t->d_flux;
+  ba.log_lya_1pz = t->d_loglya;
+  ba.noise = t->d_noise;
+  ba.omega2 = t->d_omega2;
+  ba.x = t->d_x;
+  ba.Brec = t->d_recM;
+  ba.groups = K::Groups;
+  ba.w_tiles = K::W;
+  ba.cols = K::Cols;
+  ba.group_stride = strideM;
+  ba.out = t->d_partB;
+  ba.part1 = t->d_part1;
+  hipLaunchKernelGGL(k_train_build, dim3((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H * K::Groups)), dim3(kTrCWaves * 64), kTrBuildLds, st, ba);
   TrainFactorArgs fa;
   fa.d = d;
   fa.partB = t->d_partB;
@@ -1621,16 +1612,7 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   fa.nlogp = t->d_nlogp;
   fa.not_pd = t->d_flag;
   fa.group_stride = strideD;
-  hipLaunchKernelGGL(k_train_factor<KMAX>, dim3((unsigned)(d.NQ16 * 16 / K::FQ)), dim3(K::FQ * 64), 0, st, fa);
-  ca.Aw = t->d_wB;  // dM: rows = pixels, steps over quasars
-  ca.Au = t->d_uB;
-  ca.Brec = t->d_recD;
-  ca.R = d.PG;
-  ca.steps = d.TQ;
-  ca.nsplit = d.H2;
-  ca.group_stride = strideD;
-  ca.out = t->d_partD;
-  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.PG + kTrCWaves - 1) / kTrCWaves) * d.H2 * K::Groups)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
+  hipLaunchKernelGGL(k_train_factor<KMAX>, dim3((unsigned)((d.NQ16 * 16 + TrF<KMAX>::FQ - 1) / TrF<KMAX>::FQ)), dim3(256), 0, st, fa);
   TrainCoreArgs co;
   co.d = d;
   co.recP = t->d_recP;
@@ -1638,14 +1620,28 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   co.flux = t->d_flux;
   co.log_lya_1pz = t->d_loglya;
   co.noise = t->d_noise;
-  co.omega2 = t->d_omega2;
-  co.scal = t->d_scal;
+  co.x = t->d_x;
+  co.wB = t->d_wB;
+  co.uB = t->d_uB;
   co.partcol = t->d_partcol;
   co.partsc = t->d_partsc;
   if (KMAX <= 20)
     hipLaunchKernelGGL(k_train_core, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), kTrCoreLds, st, co);
   else
     hipLaunchKernelGGL(k_train_core_wide, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), 0, st, co);
+  TrainContractArgs ca;  // dM: rows = pixels, steps over quasars
+  ca.Aw = t->d_wB;
+  ca.Au = t->d_uB;
+  ca.groups = K::Groups;
+  ca.w_tiles = K::W;
+  ca.cols = K::Cols;
+  ca.Brec = t->d_recD;
+  ca.R = d.PG;
+  ca.steps = d.TQ;
+  ca.nsplit = d.H2;
+  ca.group_stride = strideD;
+  ca.out = t->d_partD;
+  hipLaunchKernelGGL(k_train_contract, dim3((unsigned)(((d.PG + kTrCWaves - 1) / kTrCWaves) * d.H2 * K::Groups)), dim3(kTrCWaves * 64), kTrContractLds, st, ca);
   TrainFinishArgs fi;
   fi.d = d;
   fi.M = t->d_x;
@@ -1656,7 +1652,7 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   fi.f = t->d_g + nx;        // f and the not-PD flag ride behind g: one copy back
   fi.flag_in = t->d_flag;
   fi.flag_out = t->d_g + nx + 1;
-  fi.scal = t->d_scal;
+  fi.x = t->d_x;
   fi.g = t->d_g;
   hipLaunchKernelGGL(k_train_finish<KMAX>, dim3((unsigned)(G + 1)), dim3(256), 0, st, fi);
   HIP_TRY(hipMemcpyAsync(t->h_stage, t->d_g, (size_t)(nx + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1675,22 +1671,21 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
   int rc;
   if (!t->ws_ready || t->ws_class != kc) {
     training_free_workspace(t);  // another class's workspace, or what an earlier, failed attempt left behind
-    const size_t tiled = (size_t)d.NQ16 * d.T * 64;
     auto setup = [&]() -> int {
-    if ((rc = dev_alloc(&t->d_wA, tiled)) || (rc = dev_alloc(&t->d_uA, tiled)) ||
-        (rc = dev_alloc(&t->d_wB, (size_t)d.PG * d.TQ * 64)) || (rc = dev_alloc(&t->d_uB, (size_t)d.PG * d.TQ * 64)) ||
-        (rc = dev_alloc(&t->d_part1, (size_t)d.NQ16 * 16 * d.PB * 3)) ||
+    if ((rc = dev_alloc(&t->d_wB, (size_t)d.PG * d.TQ * 64)) || (rc = dev_alloc(&t->d_uB, (size_t)d.PG * d.TQ * 64)) ||
+        (rc = dev_alloc(&t->d_part1, (size_t)d.NQ16 * 16 * d.H * 3)) ||
         (rc = dev_alloc(&t->d_recM, (size_t)groups * (d.T + kTrChunk) * kTrGroupD)) || (rc = dev_alloc(&t->d_recP, (size_t)d.PG * ks * 64)) ||
         (rc = dev_alloc(&t->d_partB, (size_t)d.NQ16 * d.H * 16 * cols)) ||
         (rc = dev_alloc(&t->d_recD, (size_t)groups * (d.TQ + kTrChunk) * kTrGroupD)) || (rc = dev_alloc(&t->d_recE, (size_t)d.NQ16 * ks * 64)) ||
         (rc = dev_alloc(&t->d_nlogp, (size_t)d.NQ16 * 16)) ||
         (rc = dev_alloc(&t->d_partD, (size_t)d.PG * d.H2 * 16 * cols)) ||
-        (rc = dev_alloc(&t->d_partcol, (size_t)d.PG * d.GS * 16)) || (rc = dev_alloc(&t->d_partsc, (size_t)d.PG * d.GS * 3)) ||
-        (rc = dev_alloc(&t->d_scal, 3)))
+        (rc = dev_alloc(&t->d_partcol, (size_t)d.PG * d.GS * 16)) || (rc = dev_alloc(&t->d_partsc, (size_t)d.PG * d.GS * 3)))
       return rc;
     HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_contract),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrContractLds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_build),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrBuildLds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_core),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrCoreLds));
     return GPDLA_OK;
@@ -1778,6 +1773,7 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
   TrainingArgs a;
   a.nq = t->nq;
   a.G = G;
+  a.ld = t->ld;
   a.k = k;
   a.flux = t->d_flux;
   a.lya_1pz = t->d_lya;

@@ -22,11 +22,11 @@
 namespace gpdla {
 
 struct TrainingArgs {
-  int64_t nq, G;          // quasars, rest-frame pixels
+  int64_t nq, G, ld;      // quasars, rest-frame pixels, row stride of flux / lya_1pz / noise
   int32_t k;
-  const double *flux;     // [nq][G] (quasar-major), NaN = missing pixel (objective.m:42)
-  const double *lya_1pz;  // [nq][G]
-  const double *noise;    // [nq][G]
+  const double *flux;     // [nq][ld] (quasar-major), NaN = missing pixel (objective.m:42)
+  const double *lya_1pz;  // [nq][ld]
+  const double *noise;    // [nq][ld]
   const double *M;        // [G x k] column-major (the first G k entries of x)
   const double *omega2;   // [G] exp(2 log omega), objective.m:29
   double c_0, tau_0, beta;
@@ -50,8 +50,8 @@ __device__ __forceinline__ void training_one_quasar(const TrainingArgs &a, const
   double *s_dinv = sm, *s_y = s_dinv + G, *s_kiy = s_y + G;
   double *s_L = s_kiy + G, *s_Binv = s_L + k * k, *s_t = s_Binv + k * k, *s_z = s_t + k,
          *s_g = s_z + k, *s_red = s_g + k, *s_stage = s_red + 8;
-  const double *F = a.flux + (int64_t)q * G, *Z = a.lya_1pz + (int64_t)q * G,
-               *V = a.noise + (int64_t)q * G;
+  const double *F = a.flux + (int64_t)q * a.ld, *Z = a.lya_1pz + (int64_t)q * a.ld,
+               *V = a.noise + (int64_t)q * a.ld;
   const double log_2pi = 1.83787706640934534;  // spectrum_loss.m:17
 
   auto block_sum = [&](double v) -> double {

@@ -45,10 +45,10 @@ namespace gpdla {
 // quasar group's operands are a whole number of KiB).
 template <int KMAX> struct TrK;
 template <> struct TrK<20> {
-  static constexpr int W = 14, U = 2, Groups = 1, KsW = 53, KsU = 5, FQ = 8;
+  static constexpr int W = 14, U = 2, Groups = 1, KsW = 53, KsU = 5;
 };
 template <> struct TrK<40> {
-  static constexpr int W = 52, U = 3, Groups = 4, KsW = 205, KsU = 11, FQ = 4;
+  static constexpr int W = 52, U = 3, Groups = 4, KsW = 205, KsU = 11;
 };
 template <int KMAX> struct TrC : TrK<KMAX> {
   static constexpr int Tiles = 16 * TrK<KMAX>::Groups;          // B tiles per contraction step
@@ -65,7 +65,7 @@ struct TrainDims {
   int32_t k;
   int64_t NQ16, PG;   // row groups of 16: quasars, pixels
   int64_t T, TQ;      // contraction steps of 4: pixels (4 PG), quasars (4 NQ16)
-  int64_t PB;         // 64-pixel blocks of k_train_prepare
+  int64_t ld;         // row stride of flux / log(1+z) / noise: 16 PG (rows padded with missing pixels)
   int32_t H, H2, GS;  // splits: B build over pixels, dM over quasars, core over quasar groups
 };
 
@@ -78,18 +78,20 @@ __host__ __device__ inline void vech_ij(int c, int *i, int *j) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_train_prepare: block = (quasar group g of 16, block pb of 64 pixels), 256 threads.
-// wA/uA: [NQ16][T][jj = pixel % 4][s = quasar % 16]     A operand of the B build
-// wB/uB: [PG][TQ][jj = quasar % 4][s = pixel % 16]      A operand of the dM contraction
-// part1: [16 NQ16][PB][3] = (Sum log d, Sum y^2 w, count) of the block's pixels
+// The scalars of the parameter vector x = [M (G k) | log omega (G) | log c0, log tau0, log beta]
+// (objective.m:29-32) are exponentiated where they are used: no kernel argument changes between
+// evaluations, and no separate kernel stands in front of the first contraction.
 // ------------------------------------------------------------------------------------------
-struct TrainPrepareArgs {
-  TrainDims d;
-  const double *flux, *log_lya_1pz, *noise;  // [nq][G], NaN flux = missing pixel (objective.m:42)
-  const double *omega2;                      // [G]
-  const double *scal;                        // [3] c0, tau0, beta (k_train_scalars: exp of the last three x)
-  double *wA, *uA, *wB, *uB, *part1;
+struct TrainScal {
+  double c_0, tau_0, beta;
 };
+__device__ __forceinline__ TrainScal train_scal(const double *x, int64_t G, int k) {
+  const double *s = x + G * (k + 1);
+  return TrainScal{exp(s[0]), exp(s[1]), exp(s[2])};
+}
+__device__ __forceinline__ double train_omega2(const double *x, int64_t G, int k, int64_t p) {
+  return exp(2 * x[G * k + p]);  // objective.m:29
+}
 
 // (log(1+z) is data: it is taken once, when the training set is uploaded, so that the power of
 // spectrum_loss.m:22 costs one exp per evaluation instead of a pow)
@@ -103,68 +105,12 @@ __device__ __forceinline__ void train_element(double y, double logz1, double nu,
   *d_out = d;
 }
 
-__global__ __launch_bounds__(256) void k_train_prepare(TrainPrepareArgs a) {
-  __shared__ double sw[16][65], su[16][65];
-  const TrainDims &D = a.d;
-  const int64_t g = blockIdx.x / D.PB, pb = blockIdx.x % D.PB;
-  const int tid = threadIdx.x, pl = tid & 63, wv = tid >> 6;
-  const int64_t p = pb * 64 + pl;
-  const double c_0 = a.scal[0], tau_0 = a.scal[1], beta = a.scal[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ql = wv + 4 * i;
-    const int64_t q = g * 16 + ql;
-    double w = 0.0, u = 0.0, logd = 0.0, yy = 0.0, cnt = 0.0;
-    if (q < D.nq && p < D.G) {
-      const double y = a.flux[q * D.G + p];
-      if (!isnan(y)) {
-        double d;
-        train_element(y, a.log_lya_1pz[q * D.G + p], a.noise[q * D.G + p], a.omega2[p], c_0, tau_0, beta,
-                      &w, &u, &d);
-        logd = log(d);
-        yy = y * u;
-        cnt = 1.0;
-      }
-    }
-    sw[ql][pl] = w;
-    su[ql][pl] = u;
-    for (int o = 32; o > 0; o >>= 1) {  // the wave holds 64 pixels of ONE quasar
-      logd += __shfl_xor(logd, o);
-      yy += __shfl_xor(yy, o);
-      cnt += __shfl_xor(cnt, o);
-    }
-    if (pl == 0) {
-      double *o3 = a.part1 + ((g * 16 + ql) * D.PB + pb) * 3;
-      o3[0] = logd;
-      o3[1] = yy;
-      o3[2] = cnt;
-    }
-  }
-  __syncthreads();
-  // tiling A: 16 steps of this pixel block, 64 doubles each: [jj][s] = (pixel 4 t + jj, quasar s)
-  for (int e = tid; e < 16 * 64; e += 256) {
-    const int tl = e >> 6, l = e & 63, jj = l >> 4, s = l & 15;
-    const int64_t t = pb * 16 + tl;
-    if (t < D.T) {
-      a.wA[(g * D.T + t) * 64 + l] = sw[s][4 * tl + jj];
-      a.uA[(g * D.T + t) * 64 + l] = su[s][4 * tl + jj];
-    }
-  }
-  // tiling B: 4 pixel groups x 4 quasar steps, 64 doubles each: [jj][s] = (quasar 4 tq + jj, pixel s)
-  for (int e = tid; e < 16 * 64; e += 256) {
-    const int blk = e >> 6, l = e & 63, jj = l >> 4, s = l & 15;
-    const int pgl = blk >> 2, tql = blk & 3;
-    const int64_t pg = pb * 4 + pgl, tq = g * 4 + tql;
-    if (pg < D.PG) {
-      a.wB[(pg * D.TQ + tq) * 64 + l] = sw[4 * tql + jj][16 * pgl + s];
-      a.uB[(pg * D.TQ + tq) * 64 + l] = su[4 * tql + jj][16 * pgl + s];
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // k_train_records: from M (G x k column-major)
-// recM: [group][T + pad][16 tiles][jj = pixel % 4][col]   B[pixel 4t+jj][column] of [vech(m m') | m]
+// recM: [group][T + pad][16 tiles][jj][col]   B[pixel][column] of [vech(m m') | m]; step t = 4 c + e of
+//       chunk c contracts the pixels 16 c + 4 jj + e, jj = 0..3 (k_train_build: lane (jj, s) loads the
+//       four CONSECUTIVE pixels 16 c + 4 jj .. + 3 of quasar s and feeds them to the chunk's steps
+//       e = 0..3 -- a sum over pixels does not care in which order they are taken)
 // recP: [PG][Ks column steps][jj][col]                     B[column 4ks+jj][pixel 16pt+col], vech then m
 // ------------------------------------------------------------------------------------------
 struct TrainRecordsArgs {
@@ -172,6 +118,8 @@ struct TrainRecordsArgs {
   const double *M;
   double *recM, *recP;
   int64_t group_stride;  // doubles between the tile groups of recM: (T + chunk padding) * 16 * 64
+  int32_t *not_pd;       // cleared here, raised by k_train_factor
+  double *omega2;        // [16 PG] exp(2 log omega) (objective.m:29), zero behind the last pixel
 };
 
 __device__ __forceinline__ double train_col_value(const double *M, int64_t G, int k, int64_t p, int kind, int idx) {
@@ -191,13 +139,16 @@ __global__ void k_train_records(TrainRecordsArgs a) {
   using K = TrC<KMAX>;
   const TrainDims &D = a.d;
   const int64_t nM = D.T * K::Tiles * 64, nP = D.PG * K::Ks * 64;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.not_pd = 0;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nM + nP; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < 16 * D.PG) a.omega2[e] = e < D.G ? train_omega2(a.M, D.G, D.k, e) : 0.0;
     if (e < nM) {
       const int l = (int)(e & 63), c = (int)((e >> 6) % K::Tiles);
       const int64_t t = (e >> 6) / K::Tiles;
       const int jj = l >> 4, col = l & 15;
-      const double v = c < K::W ? train_col_value(a.M, D.G, D.k, 4 * t + jj, 0, 16 * c + col)
-                                : train_col_value(a.M, D.G, D.k, 4 * t + jj, 1, 16 * (c - K::W) + col);
+      const int64_t px = 16 * (t >> 2) + 4 * jj + (t & 3);
+      const double v = c < K::W ? train_col_value(a.M, D.G, D.k, px, 0, 16 * c + col)
+                                : train_col_value(a.M, D.G, D.k, px, 1, 16 * (c - K::W) + col);
       a.recM[(c >> 4) * a.group_stride + (t * 16 + (c & 15)) * 64 + l] = v;
     } else {
       const int64_t e2 = e - nM;
@@ -232,6 +183,8 @@ struct TrainContractArgs {
 constexpr int kTrChunk = 4;                             // steps per staged chunk
 constexpr int kTrCWaves = 4;                            // row groups (waves) per block
 constexpr size_t kTrContractLds = 2 * kTrChunk * kTrGroupD * sizeof(double);  // 64 KiB
+constexpr int kTrBuildMaxChunks = 64;  // chunks of one split of k_train_build (its omega2 table: 8 KiB)
+constexpr size_t kTrBuildLds = kTrContractLds + 16 * kTrBuildMaxChunks * sizeof(double);
 
 // NW: tiles of the block's group that take a_w (compile-time: the A operand of every MFMA is then
 // a fixed register, not a select)
@@ -320,209 +273,392 @@ __global__ __launch_bounds__(kTrCWaves * 64) void k_train_contract(TrainContract
 }
 
 // ------------------------------------------------------------------------------------------
-// k_train_factor: one wave per quasar (padded quasars write zero operands).
+// k_train_build: the first contraction with its A operand made on the fly -- [vech(B_q - I) | t_q]
+// = Sum_p [w_qp x W tiles | u_qp x U tiles] . recM.  Same block shape as k_train_contract (4 waves =
+// 4 quasar groups walking the same chunks of the same tile group; the records staged once per block,
+// double-buffered by the asynchronous copy), but lane (jj, s) loads flux / log(1+z) / noise of the
+// four consecutive pixels 16 c + 4 jj .. + 3 of quasar 16 r + s (32 contiguous bytes per array,
+// one chunk ahead), turns them into w and u in registers, and step e of the chunk takes element e:
+// no w / u array is written or read for this contraction.  The per-quasar sums of spectrum_loss.m
+// :48-52 ride along: Sum y^2 w, the pixel count, and Sum log d as log of the running product of
+// the d (mantissa and exponent kept apart: one multiply per pixel instead of one log).
+// part1: [16 NQ16][H][3] = (Sum log d, Sum y^2 w, count) of the split's pixels
+// ------------------------------------------------------------------------------------------
+struct TrainBuildArgs {
+  TrainDims d;
+  const double *flux, *log_lya_1pz, *noise;  // [nq][ld], NaN flux = missing pixel (objective.m:42)
+  const double *omega2;                      // [16 PG]
+  const double *x;                           // the parameter vector
+  const double *Brec;                        // recM
+  int32_t groups, w_tiles, cols;
+  int64_t group_stride;
+  double *out;    // partB [NQ16][H][16][cols]
+  double *part1;
+};
+
+template <int NW>
+__device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double *smem, int tg) {
+  const TrainDims &D = a.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int jj = lane >> 4, s = lane & 15;
+  const int64_t bx = blockIdx.x / a.groups;
+  const int64_t rb = bx / D.H;
+  const int h = (int)(bx % D.H);
+  const int64_t r = rb * kTrCWaves + wave;
+  const int64_t q = r * 16 + s;
+  const bool active = r < D.NQ16, qreal = q < D.nq;
+  const int64_t c0 = (D.PG * h) / D.H, c1 = (D.PG * (h + 1)) / D.H;  // chunks of 16 pixels, balanced split
+  const int nchunks = (int)(c1 - c0);
+  const TrainScal sc = train_scal(a.x, D.G, D.k);
+  d4 acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+  const int64_t row = (qreal ? q : 0) * D.ld + 4 * jj + 16 * c0;
+  const double2 *pf = reinterpret_cast<const double2 *>(a.flux + row), *pz = reinterpret_cast<const double2 *>(a.log_lya_1pz + row),
+                *pn = reinterpret_cast<const double2 *>(a.noise + row);
+  const double *brec = a.Brec + tg * a.group_stride;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t smem_lds = __builtin_amdgcn_readfirstlane(lds_address(smem));
+  auto issue_chunk = [&](int c) {
+    glds_chunk<kTrChunk * kTrGroupD / 128, kTrCWaves>(brec + (c0 + c) * kTrChunk * kTrGroupD,
+                                                      smem_lds + (uint32_t)(c & 1) * (uint32_t)(kTrChunk * kTrGroupD * 8), wave_s, lane);
+  };
+  // omega2 of the split's pixels: once per block, behind the two record buffers
+  double *om_s = smem + 2 * kTrChunk * kTrGroupD;
+  for (int e = threadIdx.x; e < 16 * nchunks; e += kTrCWaves * 64) om_s[e] = a.omega2[16 * c0 + e];
+  // The raw elements are NOT double-buffered (the registers are needed for two waves per SIMD):
+  // the first two pixels of the next chunk are requested when this chunk's second element has been
+  // used, the last two after its fourth -- two to three K-steps ahead of their use.
+  double2 f01, z01, n01, f23, z23, n23;
+  auto load01 = [&](int c) {
+    f01 = pf[(int64_t)c * 8];
+    z01 = pz[(int64_t)c * 8];
+    n01 = pn[(int64_t)c * 8];
+  };
+  auto load23 = [&](int c) {
+    f23 = pf[(int64_t)c * 8 + 1];
+    z23 = pz[(int64_t)c * 8 + 1];
+    n23 = pn[(int64_t)c * 8 + 1];
+  };
+  if (nchunks > 0) {
+    issue_chunk(0);
+    load01(0);
+    load23(0);
+  }
+  double mant = 1.0, yy = 0.0, cnt = 0.0;
+  int esum = 0;
+  auto element = [&](double y, double lz, double nv, double om, double &w, double &u) {
+    const bool ok = qreal && !isnan(y);  // rows behind the last quasar and padded / missing pixels
+    double d;
+    train_element(y, lz, nv, om, sc.c_0, sc.tau_0, sc.beta, &w, &u, &d);
+    w = ok ? w : 0.0;
+    u = ok ? u : 0.0;
+    yy += ok ? y * u : 0.0;
+    cnt += ok ? 1.0 : 0.0;
+    int ex;
+    const double m = frexp(ok ? d : 1.0, &ex);
+    mant *= m;
+    esum += ex;
+  };
+  for (int c = 0; c < nchunks; ++c) {
+    // chunk c landed (this wave's part): its copy is older than the (at most six) raw loads in flight
+    __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+    asm volatile("" ::: "memory");
+    __syncthreads();  // ... and everyone's; the other buffer's readers are done
+    if (c + 1 < nchunks) issue_chunk(c + 1);
+    const double *buf = smem + (size_t)(c & 1) * kTrChunk * kTrGroupD + lane;
+    const double *omc = om_s + 16 * c + 4 * jj;
+    const bool more = c + 1 < nchunks;
+    // element e is turned into (w, u) right in front of step e's MFMAs (the scheduling barriers keep
+    // the four elements' temporaries from being live together)
+#pragma unroll
+    for (int e = 0; e < kTrChunk; ++e) {
+      double w, u;
+      if (e == 0) element(f01.x, z01.x, n01.x, omc[0], w, u);
+      if (e == 1) element(f01.y, z01.y, n01.y, omc[1], w, u);
+      if (e == 2) element(f23.x, z23.x, n23.x, omc[2], w, u);
+      if (e == 3) element(f23.y, z23.y, n23.y, omc[3], w, u);
+      __builtin_amdgcn_sched_barrier(0);
+      if (e == 1 && more) load01(c + 1);
+      if (e == 3 && more) load23(c + 1);
+      double b[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) b[cc] = buf[(size_t)(e * 16 + cc) * 64];
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc)
+        acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < NW ? w : u, b[cc], acc[cc], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      int ex;
+      mant = frexp(mant, &ex);  // back into [1/2, 1)
+      esum += ex;
+    }
+  }
+  if (!active) return;
+  // result register rr of tile c: row (lane >> 4) + 4 rr, column 16 (16 tg + c) + (lane & 15)
+  double *o = a.out + ((r * D.H + h) * 16) * (int64_t)a.cols + 256 * tg;
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) o[(int64_t)(jj + 4 * rr) * a.cols + 16 * c + s] = acc[c][rr];
+  if (tg == 0) {
+    double logd = log(mant) + (double)esum * 0.693147180559945309;
+    for (int sh = 16; sh <= 32; sh <<= 1) {  // the four lanes of a quasar, in a fixed order
+      logd += __shfl_xor(logd, sh);
+      yy += __shfl_xor(yy, sh);
+      cnt += __shfl_xor(cnt, sh);
+    }
+    if (jj == 0) {
+      double *o3 = a.part1 + (q * D.H + h) * 3;
+      o3[0] = logd;
+      o3[1] = yy;
+      o3[2] = cnt;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kTrCWaves * 64, 2) void k_train_build(TrainBuildArgs a) {
+  extern __shared__ double smem[];
+  const int tg = (int)(blockIdx.x % a.groups);
+  const int nw = max(0, min(16, a.w_tiles - 16 * tg));  // block-uniform: 14 (k <= 20); 16, 16, 16, 4 (k <= 40)
+  if (nw == 16) train_build_body<16>(a, smem, tg);
+  else if (nw == 14) train_build_body<14>(a, smem, tg);
+  else train_build_body<4>(a, smem, tg);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_train_factor: 64 / KMAX quasars per wave, lanes along the rows (padded quasars write zero operands).
 // recD: [group][TQ + pad][16 tiles][jj = quasar % 4][col]  B[quasar][column] of [vech(T_q) | z_q]   (dM)
 // recE: [NQ16][Ks][jj = column % 4][s = quasar % 16]       A[quasar][column] of [vech2(T_q) | z_q]  (core)
 // ------------------------------------------------------------------------------------------
 struct TrainFactorArgs {
   TrainDims d;
   const double *partB;   // [NQ16][H][16][Cols]
-  const double *part1;   // [16 NQ16][PB][3]
+  const double *part1;   // [16 NQ16][H][3]
   double *recD, *recE, *nlogp;
   int32_t *not_pd;
   int64_t group_stride;  // doubles between the tile groups of recD: (TQ + chunk padding) * 16 * 64
 };
 
+// Geometry of k_train_factor: a wave factors QW quasars side by side (sub-group sg of KMAX lanes,
+// lane i of it owns row i), a block is 4 waves.
+template <int KMAX> struct TrF {
+  static constexpr int QW = 64 / KMAX;  // 3 (k <= 20), 1 (k <= 40)
+  static constexpr int Waves = 4;
+  static constexpr int FQ = QW * Waves;  // quasars per block: a whole number of quasar steps of recD
+  static_assert(FQ % 4 == 0, "a block writes whole quasar steps of recD");
+};
+
+// Orders the LDS traffic of ONE wave: lanes exchange data through LDS without a block barrier (a
+// wave's LDS instructions execute in issue order; this keeps the compiler from moving them).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int KMAX>
-__global__ __launch_bounds__(TrK<KMAX>::FQ * 64) void k_train_factor(TrainFactorArgs a) {
-  // One wave per quasar, FQ quasars per block.  Lane i owns row i of B / L in registers (static
-  // indices: the loops over KMAX are unrolled); pivots and multipliers travel by wave shuffles, L
-  // and L^-1 are shared through LDS for the inverse.  No private array is indexed at run time
-  // (that would live in scratch memory).  The two operand tilings of [T_q | z_q] are assembled in
-  // LDS and leave the block as contiguous runs (FQ of the 16 interleaved quasars of recE, FQ / 4
-  // whole quasar steps of recD).
-  // (s_sum -- the summed partials -- is dead once the rows are in registers and is reused for the
-  // recD rows; the storage of L / L^-1 likewise for the recE rows)
+__global__ __launch_bounds__(256) void k_train_factor(TrainFactorArgs a) {
+  // Lane i of a sub-group owns row i of B / L in registers (static indices: every loop over KMAX
+  // is unrolled; no private array is indexed at run time -- that would live in scratch memory).
+  // Ranks below KMAX are padded with identity rows (B = I there: L = I, log L_jj = 0, z = 0), so
+  // the code has no rank-dependent branch.  Column j of the right-looking Cholesky travels through
+  // LDS once: every lane publishes a_ij, reads the pivot a_jj and the a_cj (c > j) it needs, and
+  // takes ONE reciprocal square root -- l_ij = a_ij / sqrt(a_jj), row_c -= (a_ij / a_jj) a_cj.
+  // L, then L^-1 (column by column), then B^-1 = L^-T L^-1 and z = B^-1 t stay within the wave.
+  // The two operand tilings of [T_q | z_q] are assembled in LDS (in place: vech(B^-1) overwrites
+  // the summed partials, the recE rows the storage of L^-1) and leave the block as contiguous runs.
   using K = TrC<KMAX>;
-  constexpr int FQ = K::FQ;
-  __shared__ double s_L[FQ][KMAX * KMAX], s_Bi[FQ][KMAX * KMAX], s_sum[FQ][K::Cols], s_t[FQ][KMAX],
-      s_z[FQ][KMAX], s_sc[FQ][4];
-  static_assert(K::Ks * 4 <= KMAX * KMAX, "recE rows must fit the storage of L");
-  double (*s_outD)[K::Cols] = s_sum;
-  double (*s_outE)[KMAX * KMAX] = s_L;
+  using F = TrF<KMAX>;
+  constexpr int FQ = F::FQ, QW = F::QW;
+  __shared__ __attribute__((aligned(16))) double s_L[FQ][KMAX * KMAX];
+  __shared__ __attribute__((aligned(16))) double s_S[FQ][K::Cols];
+  __shared__ __attribute__((aligned(16))) double s_t[FQ][KMAX], s_z[FQ][KMAX], s_ld[FQ][KMAX], s_col[F::Waves][64];
+  __shared__ double s_sc[FQ][4];
+  __shared__ int s_good[FQ];
   __shared__ uint8_t s_vi[K::W * 16], s_vj[K::W * 16];
+  static_assert(K::Ks * 4 <= KMAX * KMAX, "recE rows must fit the storage of L");
+  static_assert(4 * K::KsW <= 16 * K::W && 4 * K::KsU <= 16 * K::U, "recE columns are a prefix of recD's");
   const TrainDims &D = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = D.k;
-  const int64_t q0 = (int64_t)blockIdx.x * FQ, q = q0 + wave;
+  const int64_t q0 = (int64_t)blockIdx.x * FQ, nq_pad = D.NQ16 * 16;
   const int nb = k * (k + 1) / 2;
-  for (int c = tid; c < K::W * 16; c += FQ * 64) {
+  for (int c = tid; c < K::W * 16; c += 256) {
     int i = 0, j = 0;
     if (c < nb) vech_ij(c, &i, &j);
     s_vi[c] = (uint8_t)i;
     s_vj[c] = (uint8_t)j;
   }
-  const bool real = q < D.nq;  // wave-uniform
-  const int64_t g = q >> 4;
-  const int qs = (int)(q & 15);
-  const bool mine = lane < k;
-  double *sL = s_L[wave], *sBi = s_Bi[wave], *sum = s_sum[wave], *st = s_t[wave], *sz = s_z[wave];
+  // [vech(B - I) | t] = Sum_h partial, in split order; threads along the columns (coalesced)
+  for (int e = tid; e < FQ * K::Cols; e += 256) {
+    const int ql = e / K::Cols, c = e % K::Cols;
+    const int64_t q = q0 + ql;
+    double v = 0.0;
+    if (q < D.nq) {
+      const double *pb = a.partB + (((q >> 4) * D.H) * 16 + (q & 15)) * (int64_t)K::Cols + c;
+      for (int h0 = 0; h0 < D.H; h0 += 4) {  // four loads in flight, added in split order
+        double pv[4];
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) pv[hh] = h0 + hh < D.H ? pb[(int64_t)(h0 + hh) * 16 * K::Cols] : 0.0;
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh)
+          if (h0 + hh < D.H) v += pv[hh];
+      }
+    }
+    s_S[ql][c] = v;
+  }
+  for (int e = tid; e < FQ * 3; e += 256) {
+    const int ql = e / 3, which = e % 3;
+    const int64_t q = q0 + ql;
+    double v = 0.0;
+    if (q < D.nq)
+      for (int b = 0; b < D.H; ++b) v += a.part1[(q * D.H + b) * 3 + which];
+    s_sc[ql][which] = v;
+  }
+  __syncthreads();
+
+  // lanes past the last whole sub-group shadow sub-group 0 (same reads, no writes)
+  const int sg_raw = lane / KMAX;
+  const bool valid = sg_raw < QW;
+  const int sg = valid ? sg_raw : 0, i = lane - sg_raw * KMAX;
+  const int ql = wave * QW + sg;
+  const int64_t q = q0 + ql;
+  const bool real = q < D.nq;
+  double *sL = s_L[ql], *sS = s_S[ql], *st = s_t[ql], *sz = s_z[ql];
+  double *colp = s_col[wave] + sg * KMAX;  // this sub-group's column exchange
+  double row[KMAX];  // row i of B (lower triangle), then of L
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) {
+    double v = (i < k && j <= i) ? sS[i * (i + 1) / 2 + j] : 0.0;
+    if (j == i) v += 1.0;
+    row[j] = v;
+  }
+  const double tl = i < k ? sS[K::W * 16 + i] : 0.0;
   bool pd = true;
-  double logdiag = 0.0;
-  if (real) {
-    // [vech(B - I) | t] = Sum_h partial, in split order; lanes along the columns (coalesced)
-    const double *pb = a.partB + ((g * D.H) * 16 + qs) * (int64_t)K::Cols;
+  double dinv[KMAX], my_l = 1.0;
+  // Cholesky B = L L' (spectrum_loss.m:42), right-looking
 #pragma unroll
-    for (int e = 0; e < K::Cols / 64; ++e) {
-      double v = 0.0;
-      for (int h = 0; h < D.H; ++h) v += pb[(int64_t)h * 16 * K::Cols + e * 64 + lane];
-      sum[e * 64 + lane] = v;
-    }
-    if (lane < 3) {
-      double v = 0.0;
-      for (int64_t b = 0; b < D.PB; ++b) v += a.part1[(q * D.PB + b) * 3 + lane];
-      s_sc[wave][lane] = v;
-    }
+  for (int j = 0; j < KMAX; ++j) {
+    wave_lds_sync();  // the previous column's readers are done
+    if (valid) colp[i] = row[j];
+    wave_lds_sync();
+    double acj[KMAX];
+#pragma unroll
+    for (int c = j; c < KMAX; ++c) acj[c] = colp[c];
+    const double djj = acj[j];
+    pd = pd && (djj > 0.0);
+    const double inv = rsqrt_nr(djj);  // 1 / l_jj
+    dinv[j] = inv;
+    const double lij = row[j] * inv;   // meaningful for i >= j; l_jj = a_jj / sqrt(a_jj) in lane j
+    const double lij2 = lij * inv;     // a_ij / a_jj
+    row[j] = lij;
+    if (i == j) my_l = lij;
+#pragma unroll
+    for (int c = j + 1; c < KMAX; ++c)
+      if (i >= c) row[c] = fma(-lij2, acj[c], row[c]);
   }
-  __syncthreads();
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) sL[i * KMAX + j] = j <= i ? row[j] : 0.0;
+    st[i] = tl;
+    s_ld[ql][i] = log(my_l);
+  }
+  wave_lds_sync();
+  // column i of L^-1: L x = e_i (x_r = 0 for r < i)
   double x[KMAX];
-  if (real) {
-    double row[KMAX];  // row `lane` of B (lower triangle)
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      double v = 0.0;
-      if (mine && j <= lane) {
-        v = sum[lane * (lane + 1) / 2 + j];
-        if (j == lane) v += 1.0;
-      }
-      row[j] = v;
+  for (int r = 0; r < KMAX; ++r) {
+    double s0 = r == i ? 1.0 : 0.0, s1 = 0.0;  // two chains: the dot product is latency-, not throughput-bound
+#pragma unroll
+    for (int mm = 0; mm + 1 < r; mm += 2) {  // broadcast reads, two entries at a time
+      const double2 lp = *reinterpret_cast<const double2 *>(sL + r * KMAX + mm);
+      s0 = fma(-lp.x, x[mm], s0);
+      s1 = fma(-lp.y, x[mm + 1], s1);
     }
-    const double tl = mine ? sum[K::W * 16 + lane] : 0.0;
-    // Cholesky B = L L' (spectrum_loss.m:42), right-looking
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      if (j < k) {  // wave-uniform
-        const double djj = __shfl(row[j], j);
-        pd = pd && (djj > 0.0);
-        const double ljj = sqrt(djj);
-        logdiag += log(ljj);
-        const double lij = lane == j ? ljj : row[j] / ljj;  // meaningful for lane >= j
-        row[j] = lij;
-#pragma unroll
-        for (int c = j + 1; c < KMAX; ++c) {
-          const double lcj = __shfl(lij, c);
-          if (lane >= c) row[c] = fma(-lij, lcj, row[c]);
-        }
-      }
-    }
-    if (mine) {
-#pragma unroll
-      for (int j = 0; j < KMAX; ++j)
-        if (j < k) sL[lane * k + j] = j <= lane ? row[j] : 0.0;
-      st[lane] = tl;
-    }
+    if (r & 1) s0 = fma(-sL[r * KMAX + r - 1], x[r - 1], s0);
+    x[r] = r >= i ? (s0 + s1) * dinv[r] : 0.0;
   }
-  __syncthreads();
-  if (real && pd) {
-    // column `lane` of L^-1: L x = e_lane (x_i = 0 for i < lane)
+  wave_lds_sync();  // every lane has read L: its storage now takes L^-1
+  if (valid) {
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-      double r = 0.0;
-      if (i < k) {
-        r = i == lane ? 1.0 : 0.0;
-        double r2 = 0.0;  // two chains: the dot product is latency-, not throughput-bound
+    for (int r = 0; r < KMAX; ++r) sL[r * KMAX + i] = x[r];
+  }
+  wave_lds_sync();
+  // B^-1 = L^-T L^-1: entry (i, c) = Sum_{r >= max(i, c)} Linv[r][i] Linv[r][c]; z = B^-1 t on the way
+  double zacc = 0.0;
 #pragma unroll
-        for (int mm = 0; mm < i; ++mm) {  // broadcast reads
-          if (mm & 1) r2 = fma(-sL[i * k + mm], x[mm], r2);
-          else r = fma(-sL[i * k + mm], x[mm], r);
-        }
-        r = i >= lane ? (r + r2) / sL[i * k + i] : 0.0;
-      }
-      x[i] = r;
+  for (int c0 = 0; c0 < KMAX; c0 += 4) {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = c0; r < KMAX; ++r) {  // Linv[r][c] = 0 for c > r (stored zeros)
+      const double2 l0 = *reinterpret_cast<const double2 *>(sL + r * KMAX + c0);
+      const double2 l1 = *reinterpret_cast<const double2 *>(sL + r * KMAX + c0 + 2);
+      v[0] = fma(x[r], l0.x, v[0]);
+      v[1] = fma(x[r], l0.y, v[1]);
+      v[2] = fma(x[r], l1.x, v[2]);
+      v[3] = fma(x[r], l1.y, v[3]);
     }
-  }
-  __syncthreads();  // every lane has read L: its storage now takes L^-1
-  if (real && pd && mine) {
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i)
-      if (i < k) sL[i * k + lane] = x[i];
-  }
-  __syncthreads();
-  if (real && pd && mine) {  // B^-1 = L^-T L^-1: entry (lane, c) = Sum_i Linv[i][lane] Linv[i][c]
-    for (int c0 = 0; c0 < k; c0 += 4) {  // four columns at a time: independent chains
-      double v[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int i = 0; i < KMAX; ++i)
-        if (i < k) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) v[cc] = fma(x[i], sL[i * k + min(c0 + cc, k - 1)], v[cc]);
-        }
+    const double2 t0 = *reinterpret_cast<const double2 *>(st + c0), t1 = *reinterpret_cast<const double2 *>(st + c0 + 2);
+    zacc = fma(v[0], t0.x, zacc);
+    zacc = fma(v[1], t0.y, zacc);
+    zacc = fma(v[2], t1.x, zacc);
+    zacc = fma(v[3], t1.y, zacc);
+    if (valid && i < k) {
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc)
-        if (c0 + cc < k) sBi[lane * k + c0 + cc] = v[cc];
+        if (c0 + cc <= i) sS[i * (i + 1) / 2 + c0 + cc] = v[cc];  // vech(B^-1) over the dead partial sums
     }
+  }
+  if (valid) sz[i] = zacc;
+  wave_lds_sync();
+  if (valid && i == 0) {
+    double tz = 0.0, ld = 0.0;
+    for (int c = 0; c < KMAX; ++c) {
+      tz = fma(st[c], sz[c], tz);
+      ld += s_ld[ql][c];
+    }
+    const bool good = real && pd && tz == tz && ld == ld;
+    const double log_2pi = 1.83787706640934534;  // spectrum_loss.m:17
+    const double v = 0.5 * ((s_sc[ql][1] - tz) + s_sc[ql][0] + 2 * ld + s_sc[ql][2] * log_2pi);  // :48-52
+    if (real && !good) *a.not_pd = 1;
+    s_good[ql] = good ? 1 : 0;
+    if (q < nq_pad) a.nlogp[q] = good ? v : 0.0;  // (nlogp is allocated for the padded quasar count)
   }
   __syncthreads();
-  if (real && pd && mine) {
+  // T = B^-1 + z z' in the two operand tilings (zero for padded / failed quasars): recD rows in
+  // place in s_S, recE rows (off-diagonals doubled: m'T m = Sum_{i>=j} (2 - delta_ij) T_ij m_i m_j)
+  // over the storage of L^-1
+  for (int e = tid; e < FQ * K::Cols; e += 256) {
+    const int qe = e / K::Cols, c = e % K::Cols;
+    const bool good = s_good[qe] != 0;
     double v = 0.0;
-    for (int c = 0; c < k; ++c) v = fma(sBi[lane * k + c], st[c], v);
-    sz[lane] = v;
-  }
-  __syncthreads();
-  const bool good = real && pd;
-  if (real && !pd && lane == 0) *a.not_pd = 1;
-  if (lane == 0) {
-    double v = 0.0;
-    if (good) {
-      double tz = 0.0;
-      for (int i = 0; i < k; ++i) tz = fma(st[i], sz[i], tz);
-      const double log_2pi = 1.83787706640934534;  // spectrum_loss.m:17
-      v = 0.5 * ((s_sc[wave][1] - tz) + s_sc[wave][0] + 2 * logdiag + s_sc[wave][2] * log_2pi);  // :48-52
+    if (c < K::W * 16) {
+      const int vi = s_vi[c], vj = s_vj[c];
+      if (good && c < nb) v = s_S[qe][c] + s_z[qe][vi] * s_z[qe][vj];
+      s_S[qe][c] = v;
+      if (c < 4 * K::KsW) s_L[qe][c] = vi != vj ? 2.0 * v : v;
+    } else {
+      const int cz = c - K::W * 16;
+      if (good && cz < k) v = s_z[qe][cz];
+      s_S[qe][c] = v;
+      if (cz < 4 * K::KsU) s_L[qe][4 * K::KsW + cz] = v;
     }
-    a.nlogp[q] = v;  // (nlogp is allocated for the padded quasar count)
-  }
-  // T = B^-1 + z z' in the two operand tilings (zero for padded / failed quasars)
-  for (int e = lane; e < K::Cols; e += 64) {
-    double v = 0.0;
-    if (good) {
-      if (e < K::W * 16) {
-        if (e < nb) v = sBi[s_vi[e] * k + s_vj[e]] + sz[s_vi[e]] * sz[s_vj[e]];
-      } else if (e - K::W * 16 < k) {
-        v = sz[e - K::W * 16];
-      }
-    }
-    s_outD[wave][e] = v;
-  }
-  for (int e = lane; e < K::Ks * 4; e += 64) {
-    const int ks = e >> 2, jj = e & 3;
-    double v = 0.0;
-    if (good) {
-      if (ks < K::KsW) {
-        const int c = 4 * ks + jj;
-        if (c < nb) {
-          v = sBi[s_vi[c] * k + s_vj[c]] + sz[s_vi[c]] * sz[s_vj[c]];
-          if (s_vi[c] != s_vj[c]) v *= 2.0;  // m'T m = Sum_{i>=j} (2 - delta_ij) T_ij m_i m_j
-        }
-      } else {
-        const int c = 4 * (ks - K::KsW) + jj;
-        if (c < k) v = sz[c];
-      }
-    }
-    s_outE[wave][e] = v;
   }
   __syncthreads();
   // recD: [group][tq][16 tiles][jj = quasar % 4][col]: the block's FQ quasars are FQ / 4 whole quasar steps
-  for (int e = tid; e < (FQ / 4) * K::Tiles * 64; e += FQ * 64) {
+  for (int e = tid; e < (FQ / 4) * K::Tiles * 64; e += 256) {
     const int tql = e / (K::Tiles * 64), r = e % (K::Tiles * 64);
     const int c = r >> 6, jj = (r >> 4) & 3, col = r & 15;
-    a.recD[(c >> 4) * a.group_stride + (((q0 >> 2) + tql) * 16 + (c & 15)) * 64 + (r & 63)] =
-        s_outD[4 * tql + jj][16 * c + col];
+    const int64_t tq = (q0 >> 2) + tql;
+    if (tq < D.TQ)
+      a.recD[(c >> 4) * a.group_stride + (tq * 16 + (c & 15)) * 64 + (r & 63)] = s_S[4 * tql + jj][16 * c + col];
   }
-  // recE: [g][Ks][jj = column % 4][s = quasar % 16]: FQ consecutive s per (ks, jj)
-  const int64_t g_blk = q0 >> 4;
-  const int s0 = (int)(q0 & 15);
-  for (int e = tid; e < K::Ks * 4 * FQ; e += FQ * 64) {
-    const int ql = e % FQ, kj = e / FQ;  // kj = 4 ks + jj
-    a.recE[g_blk * K::Ks * 64 + (int64_t)kj * 16 + s0 + ql] = s_outE[ql][kj];
+  // recE: [g][Ks][jj = column % 4][s = quasar % 16]
+  for (int e = tid; e < K::Ks * 4 * FQ; e += 256) {
+    const int qe = e % FQ, kj = e / FQ;  // kj = 4 ks + jj
+    const int64_t qq = q0 + qe;
+    if (qq < nq_pad) a.recE[(qq >> 4) * K::Ks * 64 + (int64_t)kj * 16 + (qq & 15)] = s_L[qe][kj];
   }
 }
 
@@ -535,15 +671,19 @@ __global__ __launch_bounds__(TrK<KMAX>::FQ * 64) void k_train_factor(TrainFactor
 struct TrainCoreArgs {
   TrainDims d;
   const double *recP, *recE;
-  const double *flux, *log_lya_1pz, *noise, *omega2;
-  const double *scal;  // [3] c0, tau0, beta
+  const double *flux, *log_lya_1pz, *noise;
+  const double *x;     // the parameter vector
+  double *wB, *uB;     // [PG][TQ][jj = quasar % 4][s = pixel % 16]: A operand of the dM contraction
   double *partcol, *partsc;
 };
 constexpr size_t kTrCoreLds = 2 * TrC<20>::Ks * 64 * sizeof(double);  // k <= 20: two quasar groups' A operands
 
 // The element-wise gradient terms of one (16 quasars x 16 pixels) tile from X = m'Tm and Y = m'z
 // (result register rr: quasar 16 g + jj + 4 rr, pixel p), accumulated into the wave's sums.
-__device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t g, int64_t p, int jj, bool active,
+// Register rr of lane (jj, s) is quasar 4 (4 g + rr) + jj, pixel s: the A-operand lane order of
+// quasar step 4 g + rr of the dM contraction, so w and u leave as whole 512-byte rows of wB / uB
+// (`ob`: this lane's offset in the pixel group's rows; zeros for missing and padded elements).
+__device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t g, int64_t p, int jj, bool active, int64_t ob,
                                                 double om, double c_0, double tau_0, double beta, const d4 &X4,
                                                 const d4 &Y4, double &col, double &gc, double &gt, double &gb) {
   const TrainDims &D = a.d;
@@ -552,20 +692,21 @@ __device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t 
   for (int rr = 0; rr < 4; ++rr) {
     const int64_t q = g * 16 + jj + 4 * rr;
     const bool ok = active && q < D.nq && p < D.G;
-    ye[rr] = ok ? a.flux[q * D.G + p] : NAN;
-    lz[rr] = ok ? a.log_lya_1pz[q * D.G + p] : 0.0;
-    nv[rr] = ok ? a.noise[q * D.G + p] : 1.0;
+    ye[rr] = ok ? a.flux[q * D.ld + p] : NAN;
+    lz[rr] = ok ? a.log_lya_1pz[q * D.ld + p] : 0.0;
+    nv[rr] = ok ? a.noise[q * D.ld + p] : 1.0;
   }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const double y = ye[rr];
+    double w = 0.0, u = 0.0;
     if (!isnan(y)) {
       const double od = tau_0 * fast_rcp(exp_nonpos(-beta * lz[rr]));  // :22 (as k_train_prepare)
       const double ab = exp_nonpos(-od);                        // :23
       const double sf = 1 - ab + c_0;                           // :26
       const double an = om * (sf * sf);                         // :27
-      const double w = fast_rcp(nv[rr] + an);                   // :29-31
-      const double u = w * y;
+      w = fast_rcp(nv[rr] + an);                                // :29-31
+      u = w * y;
       const double X = X4[rr], Y = Y4[rr];
       const double kiy = u - w * Y;                             // (K^-1 y)_p, :46
       const double diag = w - w * w * X + w * w * Y * Y;        // (K^-1)_pp = w - w^2 m'B^-1 m, :59
@@ -577,6 +718,10 @@ __device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t 
       gt = fma(core, da, gt);                                   // :70
       da = da * lz[rr] * beta;                                  // :73
       gb = fma(core, da, gb);                                   // :74
+    }
+    if (active) {
+      a.wB[ob + (4 * g + rr) * 64] = w;
+      a.uB[ob + (4 * g + rr) * 64] = u;
     }
   }
 }
@@ -616,11 +761,13 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;  // balanced split
   const int jj = lane >> 4, s = lane & 15;
   const int64_t p = pt * 16 + s;
-  const double c_0 = a.scal[0], tau_0 = a.scal[1], beta = a.scal[2];
+  const TrainScal sc = train_scal(a.x, D.G, D.k);
+  const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
   double bP[K::Ks];
 #pragma unroll
   for (int ks = 0; ks < K::Ks; ++ks) bP[ks] = active ? a.recP[(pt * K::Ks + ks) * 64 + lane] : 0.0;
-  const double om = (active && p < D.G) ? a.omega2[p] : 0.0;
+  const double om = (active && p < D.G) ? train_omega2(a.x, D.G, D.k, p) : 0.0;
+  const int64_t ob = pt * D.TQ * 64 + lane;
   static_assert((K::Ks * 64) % 128 == 0, "a quasar group's operands are a whole number of KiB");
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const uint32_t smem_lds = __builtin_amdgcn_readfirstlane(lds_address(smem));
@@ -647,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
     for (int ks = K::KsW; ks < K::Ks; ++ks)
       yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], yv, 0, 0, 0);
     const d4 xs = {x0[0] + x1[0], x0[1] + x1[1], x0[2] + x1[2], x0[3] + x1[3]};
-    train_core_tile(a, g, p, jj, active, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
+    train_core_tile(a, g, p, jj, active, ob, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
   }
   if (!active) return;
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
@@ -668,8 +815,10 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
   const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;
   const int jj = lane >> 4, s = lane & 15;
   const int64_t p = pt * 16 + s;
-  const double c_0 = a.scal[0], tau_0 = a.scal[1], beta = a.scal[2];
-  const double om = p < D.G ? a.omega2[p] : 0.0;
+  const TrainScal sc = train_scal(a.x, D.G, D.k);
+  const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
+  const double om = p < D.G ? train_omega2(a.x, D.G, D.k, p) : 0.0;
+  const int64_t ob = pt * D.TQ * 64 + lane;
   const double *bp = a.recP + pt * K::Ks * 64 + lane;
   double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
   for (int64_t g = g0; g < g1; ++g) {
@@ -687,24 +836,9 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
       yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], yv, 0, 0, 0);
     const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
                    (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
-    train_core_tile(a, g, p, jj, true, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
+    train_core_tile(a, g, p, jj, true, ob, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
   }
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
-}
-
-// exp of the three scalar parameters (objective.m:30-32) and omega2 = exp(2 log omega) (:29): on
-// the device, so that no kernel argument changes between evaluations and the whole evaluation
-// replays as one captured graph
-struct TrainScalarsArgs {
-  const double *x;   // [G (k+1) + 3]
-  int64_t G;
-  int32_t k;
-  double *omega2, *scal;
-};
-__global__ void k_train_scalars(TrainScalarsArgs a) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < a.G) a.omega2[p] = exp(2 * a.x[a.G * a.k + p]);
-  if (p < 3) a.scal[p] = exp(a.x[a.G * (a.k + 1) + p]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -720,7 +854,7 @@ struct TrainFinishArgs {
   const double *nlogp;    // [16 NQ16]
   const int32_t *flag_in; // not-PD flag of k_train_factor ...
   double *flag_out;       // ... forwarded as a double next to f (one copy back to the host)
-  const double *scal;     // [3] c0, tau0, beta: the Kim et al. priors enter the gradient (objective.m:59-71)
+  const double *x;        // tau0, beta: the Kim et al. priors enter the gradient (objective.m:59-71)
   double *f, *g;          // g: [G (k+1) + 3]
 };
 
@@ -777,8 +911,9 @@ __global__ __launch_bounds__(256) void k_train_finish(TrainFinishArgs a) {
       } else {
         double v = -s_red[0];  // :66, :70, :74
         const double tau_0_mu = 0.0023, tau_0_sigma = 0.0007, beta_mu = 3.65, beta_sigma = 0.21;  // objective.m:59-71
-        if (which == 2) v += a.scal[1] * (a.scal[1] - tau_0_mu) / (tau_0_sigma * tau_0_sigma);
-        if (which == 3) v += a.scal[2] * (a.scal[2] - beta_mu) / (beta_sigma * beta_sigma);
+        const TrainScal sc = train_scal(a.x, G, k);
+        if (which == 2) v += sc.tau_0 * (sc.tau_0 - tau_0_mu) / (tau_0_sigma * tau_0_sigma);
+        if (which == 3) v += sc.beta * (sc.beta - beta_mu) / (beta_sigma * beta_sigma);
         a.g[G * (k + 1) + (which - 1)] = v;
       }
     }
