@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1716,9 +1717,34 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
     if (e != hipSuccess) return fail(GPDLA_ERR_HIP, "training graph instantiation failed: %s", hipGetErrorString(e));
     t->graph_k = k;
   }
+#ifdef TR_EXP_TIMING
+  static double acc_l = 0, acc_s = 0, acc_m = 0, acc_gap = 0;
+  static int n_calls = 0;
+  static std::chrono::steady_clock::time_point last_end;
+  auto c0 = std::chrono::steady_clock::now();
+  if (n_calls) acc_gap += std::chrono::duration<double, std::micro>(c0 - last_end).count();
+#endif
   HIP_TRY(hipGraphLaunch(t->graph, t->stream));
+#ifdef TR_EXP_TIMING
+  auto c1 = std::chrono::steady_clock::now();
+#endif
   HIP_TRY(hipStreamSynchronize(t->stream));
+#ifdef TR_EXP_TIMING
+  auto c2 = std::chrono::steady_clock::now();
+#endif
   std::memcpy(g, t->h_stage, (size_t)nx * sizeof(double));
+#ifdef TR_EXP_TIMING
+  auto c3 = std::chrono::steady_clock::now();
+  last_end = c3;
+  acc_l += std::chrono::duration<double, std::micro>(c1 - c0).count();
+  acc_s += std::chrono::duration<double, std::micro>(c2 - c1).count();
+  acc_m += std::chrono::duration<double, std::micro>(c3 - c2).count();
+  if (++n_calls % 6 == 0) {
+    std::fprintf(stderr, "[timing] launch %.1f us, sync %.1f us, memcpy-out %.1f us, between calls (python + memcpy-in) %.1f us\n",
+                 acc_l / 6, acc_s / 6, acc_m / 6, acc_gap / 6);
+    acc_l = acc_s = acc_m = acc_gap = 0;
+  }
+#endif
   *f = t->h_stage[nx];
   if (t->h_stage[nx + 1] != 0.0)
     return fail(GPDLA_ERR_NOT_POSITIVE_DEFINITE, "B = I + M' D^-1 M not positive definite for some quasar");

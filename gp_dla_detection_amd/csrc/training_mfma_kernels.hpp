@@ -234,7 +234,9 @@ __device__ __forceinline__ void train_contract_body(const TrainContractArgs &a, 
       uc[tt] = un[tt];
     }
     glds_wait();      // chunk c landed (this wave's part) ...
+#ifndef TR_EXP_NOBAR
     __syncthreads();  // ... and everyone's; the other buffer's readers are done
+#endif
     if (c + 1 < nchunks) {
       load_a(c + 1);
       issue_chunk(c + 1);
@@ -246,7 +248,11 @@ __device__ __forceinline__ void train_contract_body(const TrainContractArgs &a, 
       if (tt < csteps) {
         double b[16];
 #pragma unroll
+#ifdef TR_EXP_NOLDS
+        for (int cc = 0; cc < 16; ++cc) b[cc] = wc[tt] + cc;
+#else
         for (int cc = 0; cc < 16; ++cc) b[cc] = buf[(size_t)(tt * 16 + cc) * 64];
+#endif
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc)
           acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? wc[tt] : uc[tt], b[cc], acc[cc], 0, 0, 0);
@@ -254,6 +260,9 @@ __device__ __forceinline__ void train_contract_body(const TrainContractArgs &a, 
     }
   }
   if (!active) return;
+#ifdef TR_EXP_NOSTORE
+  if (acc[0][0] == acc[0][0]) return;
+#endif
   // result register rr of tile c: row (lane >> 4) + 4 rr, column 16 (16 tg + c) + (lane & 15)
   double *o = a.out + ((r * a.nsplit + h) * 16) * (int64_t)a.cols + 256 * tg;
   const int jj = lane >> 4, s = lane & 15;
@@ -683,24 +692,32 @@ constexpr size_t kTrCoreLds = 2 * TrC<20>::Ks * 64 * sizeof(double);  // k <= 20
 // Register rr of lane (jj, s) is quasar 4 (4 g + rr) + jj, pixel s: the A-operand lane order of
 // quasar step 4 g + rr of the dM contraction, so w and u leave as whole 512-byte rows of wB / uB
 // (`ob`: this lane's offset in the pixel group's rows; zeros for missing and padded elements).
-__device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t g, int64_t p, int jj, bool active, int64_t ob,
+struct TrainCoreRaw {
+  double ye[4], lz[4], nv[4];
+};
+// the tile's data, requested BEFORE the tile's MFMAs so that they arrive behind them (rows are
+// padded to 16 PG pixels with missing ones: no bound on p)
+__device__ __forceinline__ void train_core_load(const TrainCoreArgs &a, int64_t g, int64_t p, int jj, bool active,
+                                                TrainCoreRaw &r) {
+  const TrainDims &D = a.d;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {  // unconditional loads (clamped row); train_core_tile drops rows behind the last quasar
+    const int64_t q = min(g * 16 + jj + 4 * rr, D.nq - 1);
+    const int64_t o = active ? q * D.ld + p : 0;
+    r.ye[rr] = a.flux[o];
+    r.lz[rr] = a.log_lya_1pz[o];
+    r.nv[rr] = a.noise[o];
+  }
+}
+__device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t g, const TrainCoreRaw &raw, int jj, bool active, int64_t ob,
                                                 double om, double c_0, double tau_0, double beta, const d4 &X4,
                                                 const d4 &Y4, double &col, double &gc, double &gt, double &gb) {
-  const TrainDims &D = a.d;
-  double ye[4], lz[4], nv[4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int64_t q = g * 16 + jj + 4 * rr;
-    const bool ok = active && q < D.nq && p < D.G;
-    ye[rr] = ok ? a.flux[q * D.ld + p] : NAN;
-    lz[rr] = ok ? a.log_lya_1pz[q * D.ld + p] : 0.0;
-    nv[rr] = ok ? a.noise[q * D.ld + p] : 1.0;
-  }
+  const double *ye = raw.ye, *lz = raw.lz, *nv = raw.nv;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const double y = ye[rr];
     double w = 0.0, u = 0.0;
-    if (!isnan(y)) {
+    if (!isnan(y) && active && g * 16 + jj + 4 * rr < a.d.nq) {
       const double od = tau_0 * fast_rcp(exp_nonpos(-beta * lz[rr]));  // :22 (as k_train_prepare)
       const double ab = exp_nonpos(-od);                        // :23
       const double sf = 1 - ab + c_0;                           // :26
@@ -778,10 +795,21 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   if (g0 < g1) issue_group(g0);
   double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
   for (int64_t g = g0; g < g1; ++g) {
-    glds_wait();
+    // group g's operands landed (this wave's part).  Their copy is older than the previous tile's
+    // eight stores of w and u, which may stay in flight (vector memory operations complete in
+    // order): waiting for those too costs a store round trip per tile.
+    if (g == g0) {
+      glds_wait();
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+      asm volatile("" ::: "memory");
+    }
     __syncthreads();
     if (g + 1 < g1) issue_group(g + 1);
     const double *re = smem + (size_t)((g - g0) & 1) * K::Ks * 64 + lane;
+    TrainCoreRaw raw;
+    train_core_load(a, g, p, jj, active, raw);
+    __builtin_amdgcn_sched_barrier(0);  // (nothing that waits for these loads may move in front of the MFMAs)
     // two accumulator chains for X (registers: the kernel must stay within 256 per lane so that
     // two waves share a SIMD), one for Y
     d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, yv = x0;
@@ -793,8 +821,9 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
 #pragma unroll
     for (int ks = K::KsW; ks < K::Ks; ++ks)
       yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], yv, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     const d4 xs = {x0[0] + x1[0], x0[1] + x1[1], x0[2] + x1[2], x0[3] + x1[3]};
-    train_core_tile(a, g, p, jj, active, ob, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
+    train_core_tile(a, g, raw, jj, active, ob, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
   }
   if (!active) return;
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
@@ -823,6 +852,9 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
   double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
   for (int64_t g = g0; g < g1; ++g) {
     const double *re = a.recE + g * K::Ks * 64 + lane;
+    TrainCoreRaw raw;
+    train_core_load(a, g, p, jj, true, raw);
+    __builtin_amdgcn_sched_barrier(0);
     d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, x2 = x0, x3 = x0, yv = x0;
     for (int ks = 0; ks + 3 < K::KsW; ks += 4) {
       x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], x0, 0, 0, 0);
@@ -834,9 +866,10 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
       x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], x0, 0, 0, 0);
     for (int ks = K::KsW; ks < K::Ks; ++ks)
       yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], yv, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
                    (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
-    train_core_tile(a, g, p, jj, true, ob, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
+    train_core_tile(a, g, raw, jj, true, ob, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
   }
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
 }

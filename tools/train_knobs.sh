@@ -1,0 +1,8 @@
+#!/bin/bash
+# Diagnostic: time of one training evaluation for several split settings (GPDLA_TRAIN_SPLITS="H,H2,GS").
+cd "$(dirname "$0")/.."
+K=${1:-20}
+for s in "6,24,24" "5,24,24" "7,24,24" "6,16,24" "6,32,24" "6,48,24" "6,24,16" "6,24,32" "6,24,48" "6,12,12"; do
+  ms=$(GPDLA_TRAIN_SPLITS=$s python3 tools/bench_training.py --k $K 2>/dev/null | python3 -c "import sys,json; print(round(1e3*json.loads(sys.stdin.readline())['gpu_seconds_per_eval'],4))")
+  echo "splits $s: $ms ms"
+done
