@@ -1229,8 +1229,8 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
     pa.nq_sub = nsub;
     pa.stride = stride;
     pa.prof = mb.prof;
-    const int64_t waves = (int64_t)nsub * 2 * ((S + 63) / 64);
-    hipLaunchKernelGGL(k_profiles, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, pa);
+    const int64_t waves = (int64_t)nsub * ((S + 63) / 64);  // one wave per 64 samples, both kinds
+    hipLaunchKernelGGL(k_profiles, dim3((unsigned)((waves + kProfWaves - 1) / kProfWaves)), dim3(kProfWaves * 64), 0, st, pa);
     HIP_TRY(hipGetLastError());
     for (int mode = 1; mode <= md; ++mode) {
       for (int pass = (mode == 1 ? 0 : 1); pass < 2; ++pass) {  // the LLS pass (mode 0) rides with model 1

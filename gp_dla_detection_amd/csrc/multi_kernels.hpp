@@ -22,13 +22,18 @@
 namespace gpdla {
 
 // ------------------------------------------------------------------------------------------
-// k_profiles: one LANE per profile (quasar, kind, sample); a wave holds 64 samples that are
-// neighbours in z_DLA (perm order), walks the padded pixels in lockstep -- the padded wavelength is
-// a wave-uniform load, the accurate Voigt tier is taken by whole waves -- and keeps the seven raw
-// values the instrument broadening needs (voigt.c:297-299) in registers: no cross-lane traffic
-// and no idle lanes (the round-1 form, one wave per profile with lanes along the pixels, paid 12
-// ds_bpermute per value and idled 6 of 64 lanes).  Outputs are transposed through LDS, 16 pixels
-// at a time, so that every store instruction writes whole 128-byte pieces of profile rows.
+// k_profiles: one LANE per sample, BOTH of its profiles (kind 0: the DLA column density, kind 1:
+// the sub-DLA one, multi :365-368).  The two share z_DLA and therefore the whole line sum
+// Sum_j c_j H(x_j) of voigt.c:282-290 -- only the column density that scales it inside the
+// exponential differs (:291) -- so a padded pixel costs one wing / accurate-tier evaluation and two
+// exponentials (round 2: one wave per (kind, 64 samples), the line sum taken twice).
+// A wave holds 64 samples that are neighbours in z_DLA (perm order) and walks the padded pixels in
+// lockstep -- the padded wavelength is a wave-uniform load, the accurate Voigt tier is taken by
+// whole waves -- and keeps the seven raw values per kind that the instrument broadening needs
+// (voigt.c:297-299) in registers: no cross-lane traffic and no idle lanes (the round-1 form, one
+// wave per profile with lanes along the pixels, paid 12 ds_bpermute per value and idled 6 of 64
+// lanes).  Outputs are transposed through LDS, 16 pixels at a time, so that every store
+// instruction writes whole 128-byte pieces of profile rows.
 // prof[((ql * 2 + kind) * S + i) * stride + p], p < stride (>= 4 * steps; entries >= n_u are 1).
 // ------------------------------------------------------------------------------------------
 struct ProfilesArgs {
@@ -44,29 +49,27 @@ struct ProfilesArgs {
   double *prof;
 };
 
-constexpr int kProfTile = 16;  // pixels per transposed store
+constexpr int kProfTile = 16;   // pixels per transposed store
+constexpr int kProfWaves = 4;   // waves per block (4 x 2 x 64 x 17 doubles of LDS: two blocks per CU)
 
-__global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
+__global__ __launch_bounds__(kProfWaves * 64) void k_profiles(ProfilesArgs a) {
   __shared__ double s_exp[kExpTab];  // 2^(j/64), the table behind exp_table()
-  __shared__ double s_out[4][64][kProfTile + 1];
+  __shared__ double s_out[kProfWaves][2][64][kProfTile + 1];
 
-  if (threadIdx.x < kExpTab) s_exp[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / kExpTab));
+  for (int e = threadIdx.x; e < kExpTab; e += kProfWaves * 64) s_exp[e] = exp2((double)e * (1.0 / kExpTab));
   __syncthreads();  // (before any wave may leave)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t wpk = (a.S + 63) / 64;                     // waves per (quasar, kind)
-  const int64_t w_global = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t ql = w_global / (2 * wpk);
+  const int64_t wpq = (a.S + 63) / 64;  // waves per quasar
+  const int64_t w_global = (int64_t)blockIdx.x * kProfWaves + wave;
+  const int64_t ql = w_global / wpq;
   if (ql >= a.nq_sub) return;
-  const int64_t rem = w_global - ql * 2 * wpk;
-  const int kind = (int)(rem / wpk);
-  const int64_t pos0 = (rem - (int64_t)kind * wpk) * 64;
+  const int64_t pos0 = (w_global - ql * wpq) * 64;
   const QuasarMeta m = a.meta[a.q0 + ql];
   if (m.status != 0) return;
   const int L = a.num_lines;
   const bool live = pos0 + lane < a.S;
   const int64_t i = a.perm[live ? pos0 + lane : a.S - 1];
   const double z_dla = m.min_z_dla + (m.max_z_dla - m.min_z_dla) * a.offset_samples[i];  // multi :309
-  const double nhi = kind ? a.lls_nhi_samples[i] : a.nhi_samples[i];
   const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
   double mult[3], ms[3];
 #pragma unroll
@@ -75,14 +78,17 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
     ms[j] = mult[j] * inv_s;
   }
   const double cs = c_light * inv_s;
-  const double nscale64 = -nhi * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;  // (pre-scaled exp, sweep_kernels.hpp)
+  // (pre-scaled exp, sweep_kernels.hpp)
+  const double nscale_a = -a.nhi_samples[i] * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;
+  const double nscale_b = -a.lls_nhi_samples[i] * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;
   const double *lam = a.lam_pad + m.lam_off;
   const int n_pad = m.n_u + 6;
-  double *rows = a.prof + ((ql * 2 + kind) * a.S) * a.stride;  // + i * stride + p
+  double *rows_a = a.prof + ((ql * 2 + 0) * a.S) * a.stride;  // + i * stride + p
+  double *rows_b = a.prof + ((ql * 2 + 1) * a.S) * a.stride;
   const double t0 = g_lines.taps[0], t1 = g_lines.taps[1], t2 = g_lines.taps[2], t3 = g_lines.taps[3],
                t4 = g_lines.taps[4], t5 = g_lines.taps[5], t6 = g_lines.taps[6];
 
-  auto raw_at = [&](int P) -> double {  // voigt.c:282-292 for this lane's sample at padded pixel P
+  auto line_sum = [&](int P) -> double {  // voigt.c:282-290 for this lane's z_DLA at padded pixel P
     const double lamP = lam[min(P, n_pad - 1)];  // wave-uniform address
     double total = 0.0;
     bool near = false;
@@ -107,11 +113,24 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
                            : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
       }
     }
-    return exp_table_scaled(nscale64 * total, s_exp);  // voigt.c:291
+    return total;
   };
+  // the two raw profiles at padded pixel P (voigt.c:291)
+#define GPDLA_PROF_RAW(P, ra, rb)                          \
+  {                                                        \
+    const double total_ = line_sum(P);                     \
+    ra = exp_table_scaled(nscale_a * total_, s_exp);       \
+    rb = exp_table_scaled(nscale_b * total_, s_exp);       \
+  }
 
-  // window of raw values P .. P+6 for output pixel P (the profile of pixel p uses padded p .. p+6)
-  double r0 = raw_at(0), r1 = raw_at(1), r2 = raw_at(2), r3 = raw_at(3), r4 = raw_at(4), r5 = raw_at(5), r6;
+  // windows of raw values P .. P+6 for output pixel P (the profile of pixel p uses padded p .. p+6)
+  double a0, a1, a2, a3, a4, a5, a6, b0, b1, b2, b3, b4, b5, b6;
+  GPDLA_PROF_RAW(0, a0, b0);
+  GPDLA_PROF_RAW(1, a1, b1);
+  GPDLA_PROF_RAW(2, a2, b2);
+  GPDLA_PROF_RAW(3, a3, b3);
+  GPDLA_PROF_RAW(4, a4, b4);
+  GPDLA_PROF_RAW(5, a5, b5);
   const int64_t nrows = min((int64_t)64, a.S - pos0);
   // the 16 profile rows this lane stores into (store instruction e writes rows 4e .. 4e+3): their
   // offsets once, not a perm look-up and a 64-bit multiply per store
@@ -124,16 +143,25 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
   for (int p0 = 0; p0 < m.n_u; p0 += kProfTile) {
 #pragma unroll
     for (int tt = 0; tt < kProfTile; ++tt) {
-      r6 = raw_at(p0 + tt + 6);
-      double acc = r0 * t0;  // voigt.c:297-299, taps in ascending order
-      acc = fma(r1, t1, acc);
-      acc = fma(r2, t2, acc);
-      acc = fma(r3, t3, acc);
-      acc = fma(r4, t4, acc);
-      acc = fma(r5, t5, acc);
-      acc = fma(r6, t6, acc);
-      s_out[wave][lane][tt] = acc;
-      r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6;
+      GPDLA_PROF_RAW(p0 + tt + 6, a6, b6);
+      double acc = a0 * t0;  // voigt.c:297-299, taps in ascending order
+      acc = fma(a1, t1, acc);
+      acc = fma(a2, t2, acc);
+      acc = fma(a3, t3, acc);
+      acc = fma(a4, t4, acc);
+      acc = fma(a5, t5, acc);
+      acc = fma(a6, t6, acc);
+      s_out[wave][0][lane][tt] = acc;
+      acc = b0 * t0;
+      acc = fma(b1, t1, acc);
+      acc = fma(b2, t2, acc);
+      acc = fma(b3, t3, acc);
+      acc = fma(b4, t4, acc);
+      acc = fma(b5, t5, acc);
+      acc = fma(b6, t6, acc);
+      s_out[wave][1][lane][tt] = acc;
+      a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = a5; a5 = a6;
+      b0 = b1; b1 = b2; b2 = b3; b3 = b4; b4 = b5; b5 = b6;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -143,16 +171,23 @@ __global__ __launch_bounds__(256) void k_profiles(ProfilesArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int rl = 4 * e + (lane >> 4);
-      if (roff[e] >= 0 && in_row) rows[roff[e] + p0] = s_out[wave][rl][tt];
+      if (roff[e] >= 0 && in_row) {
+        // (non-temporal: the table is 15 GB per sub-batch and is next read by another kernel)
+        __builtin_nontemporal_store(s_out[wave][0][rl][tt], &rows_a[roff[e] + p0]);
+        __builtin_nontemporal_store(s_out[wave][1][rl][tt], &rows_b[roff[e] + p0]);
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
+#undef GPDLA_PROF_RAW
   // padding behind the pixels: 1 (no absorption)
   for (int64_t rl = 0; rl < nrows; ++rl) {
     const int64_t ir = a.perm[pos0 + rl];
-    for (int64_t p = m.n_u + lane; p < a.stride; p += 64) rows[ir * a.stride + p] = 1.0;
+    for (int64_t p = m.n_u + lane; p < a.stride; p += 64) {
+      rows_a[ir * a.stride + p] = 1.0;
+      rows_b[ir * a.stride + p] = 1.0;
+    }
   }
-
 }
 
 // ------------------------------------------------------------------------------------------
