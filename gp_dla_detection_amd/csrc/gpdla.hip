@@ -174,6 +174,13 @@ struct gpdla_context {
   // context; destroying the context first orphans them (ctx = nullptr) instead of leaving that
   // pointer dangling, so gpdla_batch_destroy is safe in either order.
   std::vector<gpdla_batch *> batches;
+  // The multi-DLA profile table (k_profiles -> k_sweep_multi, up to cfg.multi_profile_bytes, 16 GiB
+  // by default) is scratch of one process call: it belongs to the context, is allocated once and
+  // grows only.  multi_mu keeps two threads' gpdla_batch_process_multi calls on this context from
+  // interleaving their launches (the launches of one call are ordered on `stream`).
+  double *d_prof = nullptr;
+  size_t prof_capacity = 0;  // doubles
+  std::mutex multi_mu;
 };
 
 struct gpdla_batch {
@@ -219,20 +226,32 @@ struct gpdla_batch {
 
 struct MultiBuffers {
   double *sll_dla = nullptr, *sll_lls = nullptr, *ll_no = nullptr, *ll_dla = nullptr, *ll_lls = nullptr;
-  double *map_z = nullptr, *map_n = nullptr, *map_i = nullptr, *prof = nullptr;
+  double *map_z = nullptr, *map_n = nullptr, *map_i = nullptr;
   double *lp_lls = nullptr, *lp_dla = nullptr;
   double *post = nullptr, *scal = nullptr;  // scal: lpost_no, lpost_lls, p_no, p_lls, p_dla [5][nq]; lpost_dla after
   double *summary = nullptr;                // [nq][GPDLA_SUMMARY_COLS_MULTI(md)]
   uint32_t *base = nullptr;
   int32_t *alive = nullptr;
-  int64_t prof_quasars = 0, prof_stride = 0;
+  // what the result tables / the prior arrays were allocated for: a re-filled batch slot keeps them
+  // while it does not grow (the tables are indexed per quasar, so spare rows behind nq are unused)
+  int64_t cap_nq = 0, cap_S = 0, lp_cap_nq = 0;
+  int cap_md = 0, lp_cap_md = 0;
+  int64_t prof_quasars = 0, prof_stride = 0;  // sub-batching of the context's profile table for this batch
   bool processed = false;
+  void free_tables() {
+    for (void **p : {(void **)&sll_dla, (void **)&sll_lls, (void **)&ll_no, (void **)&ll_dla, (void **)&ll_lls,
+                     (void **)&map_z, (void **)&map_n, (void **)&map_i, (void **)&post, (void **)&scal,
+                     (void **)&summary, (void **)&base, (void **)&alive}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    cap_nq = cap_S = 0;
+    cap_md = 0;
+  }
   ~MultiBuffers() {
-    for (void *p : {(void *)sll_dla, (void *)sll_lls, (void *)ll_no, (void *)ll_dla, (void *)ll_lls,
-                    (void *)map_z, (void *)map_n, (void *)map_i, (void *)prof, (void *)lp_lls,
-                    (void *)lp_dla, (void *)post, (void *)scal, (void *)summary, (void *)base,
-                    (void *)alive})
-      if (p) (void)hipFree(p);
+    free_tables();
+    if (lp_lls) (void)hipFree(lp_lls);
+    if (lp_dla) (void)hipFree(lp_dla);
   }
 };
 
@@ -310,6 +329,7 @@ void gpdla_context_destroy(gpdla_context *c) {
   dev_free(c->d_log_nhi);
   dev_free(c->d_lls_nhi);
   dev_free(c->d_perm);
+  dev_free(c->d_prof);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -320,7 +340,14 @@ void gpdla_context_destroy(gpdla_context *c) {
 
 int gpdla_context_set_stream(gpdla_context *c, void *hip_stream) {
   if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  hipStream_t next = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (next != c->stream && c->d_prof) {
+    // work queued on the old stream may still use the context's profile table, which the next
+    // multi-DLA call (on the new stream) overwrites
+    HIP_TRY(hipSetDevice(c->device_id));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  c->stream = next;
   return GPDLA_OK;
 }
 
@@ -586,10 +613,25 @@ int batch_fill(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, int md
   if (!md) {
     chk(put(b->d_lp_dla, sp->log_priors_dla, nqs * 8));
   } else {  // multi-DLA batch: [nq][max_dlas] DLA priors + the sub-DLA prior (multi :204-210)
-    delete b->mb;  // result tables are sized by nq: rebuilt by the next gpdla_batch_process_multi
-    b->mb = new MultiBuffers();
-    chk(upload(&b->mb->lp_dla, sp->log_priors_dla, nqs * md, st));
-    chk(upload(&b->mb->lp_lls, sp->log_priors_lls, nqs, st));
+    if (!b->mb) b->mb = new MultiBuffers();
+    MultiBuffers &mb = *b->mb;
+    mb.processed = false;  // (the result tables are kept: gpdla_batch_process_multi regrows them if needed)
+    if (mb.lp_cap_nq < nq || mb.lp_cap_md != md) {
+      dev_free(mb.lp_dla);
+      dev_free(mb.lp_lls);
+      mb.lp_dla = mb.lp_lls = nullptr;
+      mb.lp_cap_nq = 0;
+      chk(dev_alloc(&mb.lp_dla, nqs * md));
+      chk(dev_alloc(&mb.lp_lls, nqs));
+      if (!rc) {
+        mb.lp_cap_nq = nq;
+        mb.lp_cap_md = md;
+      }
+    }
+    if (!rc) {
+      chk(put(mb.lp_dla, sp->log_priors_dla, nqs * md * 8));
+      chk(put(mb.lp_lls, sp->log_priors_lls, nqs * 8));
+    }
   }
   chk(put(b->d_meta, meta.data(), nqs * sizeof(QuasarMeta)));
   chk(put(b->d_order, order.data(), nqs * 4));
@@ -1126,36 +1168,53 @@ int launch_sweep_multi_split(gpdla_context *c, const SweepMultiArgs &args) {
   }
 }
 
-// Result tables of a multi-DLA batch, allocated on first use.
+// Result tables of a multi-DLA batch (allocated on first use, kept while the batch does not grow)
+// and the context's profile table.
 int multi_alloc(gpdla_batch *b) {
   MultiBuffers &mb = *b->mb;
-  if (mb.sll_dla) return GPDLA_OK;
+  gpdla_context *c = b->ctx;
   const size_t nqs = (size_t)b->nq, S = (size_t)b->S;
   const int md = b->md;
   int rc = GPDLA_OK;
   auto chk = [&](int x) { if (x && !rc) rc = x; };
-  chk(dev_alloc(&mb.sll_dla, nqs * md * S));
-  chk(dev_alloc(&mb.sll_lls, nqs * S));
-  chk(dev_alloc(&mb.ll_no, nqs));
-  chk(dev_alloc(&mb.ll_dla, nqs * md));
-  chk(dev_alloc(&mb.ll_lls, nqs));
-  chk(dev_alloc(&mb.map_z, nqs * md * md));
-  chk(dev_alloc(&mb.map_n, nqs * md * md));
-  chk(dev_alloc(&mb.map_i, nqs * md * md));
-  chk(dev_alloc(&mb.base, nqs * (md > 1 ? md - 1 : 1) * S));
-  chk(dev_alloc(&mb.alive, nqs));
-  chk(dev_alloc(&mb.post, nqs * (2 + md)));
-  chk(dev_alloc(&mb.scal, nqs * (5 + md)));
-  chk(dev_alloc(&mb.summary, nqs * GPDLA_SUMMARY_COLS_MULTI(md)));
-  if (rc) return rc;
+  if (mb.sll_dla && (b->nq > mb.cap_nq || b->S != mb.cap_S || md != mb.cap_md)) mb.free_tables();
+  if (!mb.sll_dla) {
+    chk(dev_alloc(&mb.sll_dla, nqs * md * S));
+    chk(dev_alloc(&mb.sll_lls, nqs * S));
+    chk(dev_alloc(&mb.ll_no, nqs));
+    chk(dev_alloc(&mb.ll_dla, nqs * md));
+    chk(dev_alloc(&mb.ll_lls, nqs));
+    chk(dev_alloc(&mb.map_z, nqs * md * md));
+    chk(dev_alloc(&mb.map_n, nqs * md * md));
+    chk(dev_alloc(&mb.map_i, nqs * md * md));
+    chk(dev_alloc(&mb.base, nqs * (md > 1 ? md - 1 : 1) * S));
+    chk(dev_alloc(&mb.alive, nqs));
+    chk(dev_alloc(&mb.post, nqs * (2 + md)));
+    chk(dev_alloc(&mb.scal, nqs * (5 + md)));
+    chk(dev_alloc(&mb.summary, nqs * GPDLA_SUMMARY_COLS_MULTI(md)));
+    if (rc) {
+      mb.free_tables();
+      return rc;
+    }
+    mb.cap_nq = b->nq;
+    mb.cap_S = b->S;
+    mb.cap_md = md;
+  }
   // profile table: rows of `stride` doubles, 2 S rows per quasar, sub-batches sized to the budget
   const int64_t stride = ((4 * ((b->max_pix + 3) / 4) + 4 + 15) / 16) * 16;
   const double per_q = 2.0 * (double)S * (double)stride * sizeof(double);
-  const double budget = b->ctx->cfg.multi_profile_bytes > 0 ? (double)b->ctx->cfg.multi_profile_bytes
-                                                            : 16.0 * 1073741824.0;
+  const double budget = c->cfg.multi_profile_bytes > 0 ? (double)c->cfg.multi_profile_bytes : 16.0 * 1073741824.0;
   int64_t nq_sub = (int64_t)std::max(1.0, std::floor(budget / per_q));
   nq_sub = std::min(nq_sub, b->nq);
-  if ((rc = dev_alloc(&mb.prof, (size_t)nq_sub * 2 * S * stride))) return rc;
+  const size_t need = (size_t)nq_sub * 2 * S * stride;
+  if (c->prof_capacity < need) {
+    HIP_TRY(hipStreamSynchronize(c->stream));  // an earlier call's sweeps may still read the old table
+    dev_free(c->d_prof);
+    c->d_prof = nullptr;
+    c->prof_capacity = 0;
+    if ((rc = dev_alloc(&c->d_prof, need))) return rc;
+    c->prof_capacity = need;
+  }
   mb.prof_quasars = nq_sub;
   mb.prof_stride = stride;
   return GPDLA_OK;
@@ -1184,6 +1243,7 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
         return fail(GPDLA_ERR_INVALID_ARGUMENT, "base_sample_inds[%zu] = %u exceeds num_dla_samples = %lld",
                     e, base_in[e], (long long)S);
   HIP_TRY(hipSetDevice(c->device_id));
+  std::lock_guard<std::mutex> multi_lock(c->multi_mu);  // the profile table is the context's: one call's launches at a time
   hipStream_t st = c->stream;
   int rc = multi_alloc(b);
   if (rc) return rc;
@@ -1228,7 +1288,7 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
     pa.q0 = q0;
     pa.nq_sub = nsub;
     pa.stride = stride;
-    pa.prof = mb.prof;
+    pa.prof = c->d_prof;
     const int64_t waves = (int64_t)nsub * ((S + 63) / 64);  // one wave per 64 samples, both kinds
     hipLaunchKernelGGL(k_profiles, dim3((unsigned)((waves + kProfWaves - 1) / kProfWaves)), dim3(kProfWaves * 64), 0, st, pa);
     HIP_TRY(hipGetLastError());
@@ -1237,7 +1297,7 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
         SweepMultiArgs sa;
         sa.meta = b->d_meta;
         sa.records = b->d_records;
-        sa.prof = mb.prof;
+        sa.prof = c->d_prof;
         sa.base_inds = mb.base;
         sa.alive = mb.alive;
         sa.S = S;

@@ -365,7 +365,7 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
     yy += ok ? y * u : 0.0;
     cnt += ok ? 1.0 : 0.0;
     int ex;
-    const double m = frexp(ok ? d : 1.0, &ex);
+    const double m = frexp(ok ? (d > 0.0 ? d : NAN) : 1.0, &ex);  // a non-positive variance poisons the sum (reported as not positive definite)
     mant *= m;
     esum += ex;
   };
@@ -627,9 +627,9 @@ __global__ __launch_bounds__(256) void k_train_factor(TrainFactorArgs a) {
       tz = fma(st[c], sz[c], tz);
       ld += s_ld[ql][c];
     }
-    const bool good = real && pd && tz == tz && ld == ld;
     const double log_2pi = 1.83787706640934534;  // spectrum_loss.m:17
     const double v = 0.5 * ((s_sc[ql][1] - tz) + s_sc[ql][0] + 2 * ld + s_sc[ql][2] * log_2pi);  // :48-52
+    const bool good = real && pd && v == v;  // (NaN: a pivot, or a variance d, that was not positive)
     if (real && !good) *a.not_pd = 1;
     s_good[ql] = good ? 1 : 0;
     if (q < nq_pad) a.nlogp[q] = good ? v : 0.0;  // (nlogp is allocated for the padded quasar count)
