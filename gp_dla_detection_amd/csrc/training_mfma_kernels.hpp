@@ -18,16 +18,19 @@
 // vech(m m') with vech(T) (off-diagonals doubled), i.e. the third contraction -- over the
 // k(k+1)/2 + k columns -- and every contraction runs on v_mfma_f64_16x16x4_f64.
 //
-// Kernels (k <= 20; 14 w-tiles + 2 u-tiles of 16 columns):
-//   k_train_prepare   elementwise w, u from (flux, 1+z, noise); written in the two lane-ordered
-//                     tilings the contractions read, through an LDS transpose; per-quasar partial
-//                     sums of log d, y^2 w and the pixel count
-//   k_train_records   [vech(m m') | m] from M in the two B-operand tilings
-//   k_train_contract  rows x steps MFMA contraction, used twice: B/t (rows = quasars, steps over
-//                     pixels) and dM (rows = pixels, steps over quasars); split along the step axis
-//                     into partial sums that the next kernel adds in a fixed order
-//   k_train_factor    per quasar: Cholesky, B^-1, z, -log p; T_q and z_q in both operand tilings
-//   k_train_core      m'z and m'Tm by MFMA, then the element-wise gradient terms and their sums
+// Kernels (k <= 20: 14 w-tiles + 2 u-tiles of 16 columns; k <= 40: four such tile groups):
+//   k_train_records   [vech(m m') | m] from M in the two B-operand tilings; omega2 = exp(2 log omega)
+//   k_train_build     first contraction, rows = quasars, steps over pixels, with its A operand made on
+//                     the fly: w, u from (flux, log(1+z), noise) in registers, never stored; the
+//                     per-quasar sums of log d (as a running product), y^2 w and the pixel count ride
+//                     along; split along the pixel axis into partial sums
+//   k_train_factor    per quasar: partials added in split order, Cholesky (64 / KMAX quasars per wave,
+//                     lanes along the rows), B^-1, z, -log p; T_q and z_q in both operand tilings
+//   k_train_core      m'z and m'Tm by MFMA, then the element-wise gradient terms and their sums; its
+//                     result registers hold w and u in the A-operand lane order of the dM contraction,
+//                     which it writes out as whole rows (wB, uB)
+//   k_train_contract  rows x steps MFMA contraction for dM (rows = pixels, steps over quasars), split
+//                     along the step axis into partial sums that the next kernel adds in a fixed order
 //   k_train_finish    ordered sums of all partials into f and g
 #pragma once
 #include <hip/hip_runtime.h>

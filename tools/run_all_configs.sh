@@ -17,5 +17,6 @@ run python3 bench.py --no-cpu-baseline --contraction f32                        
 run python3 bench.py --no-cpu-baseline --contraction f32 --k 40 --spectra 256   # config 5: fp32 contraction, k = 40
 run python3 tools/bench_multi.py --spectra 64                                   # config 4: multi-DLA driver, resident
 run python3 tools/bench_multi.py --spectra 64 --k 40 --max-dlas 3               # config 4 shape at k = 40
-run python3 tools/bench_training.py                                             # N3: training objective
+run python3 tools/bench_training.py                                             # N3: training objective, k = 20
+run python3 tools/bench_training.py --k 40                                      # N3: training objective, k = 40
 echo "wrote $OUT"
