@@ -191,3 +191,56 @@ def test_gpu_mean_flux_suppression_against_the_references_own_python(golden):
         inside = (wl / (1 + z) >= p.min_lambda) & (wl / (1 + z) <= p.max_lambda)   # process_qsos.m:104-105
         assert rows.shape[0] == inside.sum() and rows.shape[0] > 300
         assert np.abs(rows[:, 1] / g[f"scale_{i}"][inside] - 1).max() < 1e-13, i
+
+
+def test_batches_of_one_context_share_the_profile_table(oracle):
+    """The profile table is scratch of one process call and belongs to the context: two batches
+    processed back to back on one context (the second larger, so the table grows while the first
+    one's results are still on the GPU), a slot re-filled with fewer and then with more quasars
+    (result tables kept, regrown), and supplied indices give what separate calls give."""
+    p = MultiParameters(max_dlas=3)
+    model = synthetic.make_model(20)
+    S = 96
+    samples = synthetic.make_samples(S)
+    A = [synthetic.make_spectrum(300 + i, n, model) for i, n in enumerate([150, 90])]
+    B = [synthetic.make_spectrum(400 + i, n, model, mask_fraction=0.04) for i, n in enumerate([260, 333, 120, 201])]
+    C = [synthetic.make_spectrum(500, 77, model)]
+    sets = {"A": A, "B": B, "C": C}
+    rng = np.random.default_rng(5)
+    bsi = {k: rng.integers(1, S + 1, size=(len(v), p.max_dlas - 1, S), dtype=np.uint32) for k, v in sets.items()}
+    lp = {k: priors(v, p) for k, v in sets.items()}
+    ref = {k: gp.process_qsos_multiple_dlas_meanflux(model, samples, v, lp[k], params=p, base_sample_inds=bsi[k])
+           for k, v in sets.items()}
+
+    def same(got, want):
+        for key in ("sample_log_likelihoods_dla", "sample_log_likelihoods_lls", "log_likelihoods_dla",
+                    "log_likelihoods_lls", "log_likelihoods_no_dla", "model_posteriors", "MAP_inds"):
+            np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+    ctx = gp.Context(0, p)
+    try:
+        ctx.set_model(model)
+        ctx.set_samples(samples)
+        up = lambda k: (sets[k], lp[k][0], lp[k][2], lp[k][1])  # noqa: E731
+        ba, bb = ctx.upload(*up("A")), ctx.upload(*up("B"))
+        ba.process_multi(bsi["A"])
+        bb.process_multi(bsi["B"])   # grows the context's table behind A's sweeps
+        same(bb.download_multi(), ref["B"])
+        same(ba.download_multi(), ref["A"])   # A's result tables are its own
+        ba.reload(*up("C"))                   # fewer quasars: tables kept
+        ba.process_multi(bsi["C"])
+        same(ba.download_multi(), ref["C"])
+        ba.reload(*up("B"))                   # more quasars than the slot ever held: tables regrown
+        ba.process_multi(bsi["B"])
+        same(ba.download_multi(), ref["B"])
+        from gp_dla_detection_amd import _lib
+        with pytest.raises(_lib.GpdlaError):  # re-filled, not yet processed: nothing to download
+            bb.reload(*up("A"))
+            bb.download_multi()
+        ba.close()
+        bb.close()
+    finally:
+        ctx.close()
+    # and against the oracle, once
+    r = oracle_multi(oracle, model, samples, C[0], bsi["C"][0], p)
+    compare(ref["C"], 0, r, p)
