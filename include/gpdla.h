@@ -125,7 +125,10 @@ typedef struct {
    * quadratic form, log-determinant, Cholesky) in fp64.  Not parity-grade; single-DLA sweep only. */
   int32_t contraction_precision;
   /* multi-DLA driver: bytes of HBM the per-quasar Voigt profile table (2 S rows per quasar) may take
-   * at a time; quasars are swept in sub-batches that fit.  0 = default (16 GiB). */
+   * at a time; quasars are swept in sub-batches that fit.  0 = default (16 GiB).  The table is
+   * scratch of one gpdla_batch_process_multi call and belongs to the CONTEXT: it is allocated on
+   * first use, grows only, is shared by all batches of the context and freed with it (the calls of
+   * one context are serialized on its stream; two threads' calls take turns). */
   int64_t multi_profile_bytes;
   /* single-DLA sweep: bytes of HBM the per-K-step records of a batch may take at a time.  A batch
    * whose records exceed it is swept in groups of quasars (records built, then swept, group after
