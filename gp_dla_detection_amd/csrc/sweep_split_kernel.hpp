@@ -188,7 +188,9 @@ __global__ __launch_bounds__(512) void k_sweep_split(SweepArgs a) {
       const int c = 2 * it + hc;
       if (c < nchunks) {  // block-uniform
         __builtin_amdgcn_s_waitcnt(0x0F70);  // (see k_sweep: free here, keeps compiler waits out of the K-steps)
+#ifndef SPLIT_EXP_NODMA
         if (c + 1 < nchunks) issue_chunk(c + 1);
+#endif
         if (hc == 0) {
           // operands of this iteration's stages W and R: requested now (behind the vmcnt drain
           // above, so it does not wait for them), used after the K-steps of the second chunk
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(512) void k_sweep_split(SweepArgs a) {
               acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < NTW - kTail ? w : a_tail, bop[cc], acc[cc], 0, 0, 0);
           }
         }
+#ifndef SPLIT_EXP_NOWR
         if (hc == 1) {
           // stages W and R of this role, for the next iteration and the one after the next two
           double w1, u1;
@@ -220,8 +223,11 @@ __global__ __launch_bounds__(512) void k_sweep_split(SweepArgs a) {
           *wu_slot(par ^ 1, 1, role) = u1;
           my_ring[(4 * t_r + jj) & 63] = raw_of(lam_r);
         }
+#endif
         glds_wait();
+#ifndef SPLIT_EXP_NOBAR
         __syncthreads();
+#endif
       } else if (hc == 1) {
         // odd number of chunks: the last iteration has no second chunk, but stages W/R and the
         // barrier structure must stay uniform (nothing consumes them; skip the work, keep the sync)

@@ -4,7 +4,7 @@
 # three rounds, and prints the sweep kernel's average launch time per variant.
 # Make variants with tools/ab_build.sh <name> (compiles the working tree into build/ab/<name>.so).
 cd "$(dirname "$0")/.."
-for round in 1 2 3; do
+for round in ${AB_ROUNDS:-1 2 3}; do
   for so in build/ab/*.so; do
     GPDLA_LIB_PATH=$PWD/$so python bench.py --no-cpu-baseline "$@" 2>/dev/null \
       | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$so', round(d['roofline']['kernel_ms'],2), round(d['roofline']['frac'],4))"
