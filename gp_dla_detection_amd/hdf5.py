@@ -661,6 +661,64 @@ class Reference:
         self.addr = int(addr)
 
 
+class ChunkedDatasetStream:
+    """See :meth:`FileWriter.open_chunked_dataset`."""
+
+    def __init__(self, w: "FileWriter", name: str, shape, dtype, chunks, attrs):
+        self.w = w
+        self.parent, self.leaf = w._split(name)
+        self.shape = tuple(int(x) for x in shape)
+        self.chunks = tuple(int(c) for c in chunks)
+        dt = np.dtype(dtype)
+        self.dt = dt.newbyteorder("<") if dt.byteorder == ">" else dt
+        if len(self.chunks) != len(self.shape) or not self.shape or any(c < 1 for c in self.chunks):
+            raise HDF5Error("chunks must give one positive extent per dimension")
+        self.attrs = dict(attrs or {})
+        self.entries = {}
+        w._groups[self.parent][self.leaf] = UNDEF  # the name is taken; the address comes with close()
+
+    def write_chunk(self, offsets, block) -> None:
+        """``block``: the data at ``offsets`` (multiples of the chunk extents), at most one chunk
+        large; what it lacks of a full chunk (the dataset's ragged edge) is zero-filled."""
+        offsets = tuple(int(o) for o in offsets)
+        if len(offsets) != len(self.shape) or any(o % c or o >= max(s, 1) for o, c, s in zip(offsets, self.chunks, self.shape)):
+            raise HDF5Error(f"chunk offsets {offsets} are not on the chunk grid of a {self.shape} dataset")
+        if offsets in self.entries:
+            raise HDF5Error(f"chunk {offsets} written twice")
+        block = np.asarray(block, dtype=self.dt)
+        if block.ndim != len(self.shape) or any(b > c for b, c in zip(block.shape, self.chunks)):
+            raise HDF5Error(f"block of shape {block.shape} exceeds the chunk {self.chunks}")
+        if block.shape != self.chunks:
+            full = np.zeros(self.chunks, dtype=self.dt)
+            full[tuple(slice(0, b) for b in block.shape)] = block
+            block = full
+        block = np.ascontiguousarray(block)
+        self.w._align(8)
+        addr = self.w._pos
+        block.tofile(self.w._f)
+        self.w._pos += block.nbytes
+        self.entries[offsets] = (block.nbytes, addr)
+
+    def close(self) -> "Reference":
+        grid = [range(0, max(s, 1), c) for s, c in zip(self.shape, self.chunks)]
+        want = int(np.prod([len(g) for g in grid]))
+        if len(self.entries) != want:
+            raise HDF5Error(f"{self.leaf}: {len(self.entries)} of {want} chunks were written")
+        entries = [(o, self.entries[o][0], self.entries[o][1]) for o in sorted(self.entries)]
+        btree = self.w._write_chunk_btree(entries, self.chunks)
+        nd = len(self.shape)
+        msgs = [_message(MSG_DATASPACE, _dataspace_message(self.shape)),
+                _message(MSG_DATATYPE, _dtype_message(self.dt), flags=1),
+                _message(MSG_FILL, _fill_message(3)),
+                _message(MSG_LAYOUT, struct.pack("<BBB", 3, 2, nd + 1) + struct.pack("<Q", btree) + struct.pack(
+                    f"<{nd + 1}I", *self.chunks, self.dt.itemsize))]
+        for k, v in self.attrs.items():
+            msgs.append(_attribute_message(k, v))
+        addr = self.w._write_object_header(msgs)
+        self.w._groups[self.parent][self.leaf] = addr
+        return Reference(addr)
+
+
 class FileWriter:
     """Sequential HDF5 writer.  Objects are appended as they are created; the groups' symbol tables
     and the superblock are written by :meth:`close`.
@@ -817,7 +875,6 @@ class FileWriter:
         return self._append(head + body)
 
     def _write_chunks(self, arr, chunks, filters) -> int:
-        nd = arr.ndim
         grid = [range(0, max(s, 1), c) for s, c in zip(arr.shape, chunks)]
         entries = []  # (offsets, size, address)
         for idx in np.ndindex(*[len(g) for g in grid]):
@@ -829,8 +886,14 @@ class FileWriter:
             for fid, cd in filters:
                 raw = _shuffle(raw, cd[0]) if fid == 2 else zlib.compress(raw, cd[0])
             entries.append((offs, len(raw), self._append(raw)))
+        return self._write_chunk_btree(entries, chunks)
+
+    def _write_chunk_btree(self, entries, chunks) -> int:
+        """The version-1 B-tree that indexes a chunked dataset's chunks: ``entries`` = (offsets,
+        stored size, address), in ascending offset order."""
         if not entries:
             return UNDEF
+        nd = len(chunks)
         ksize = 8 + 8 * (nd + 1)
         cap = 2 * self.CHUNK_K
         node_bytes = 24 + (cap + 1) * ksize + cap * 8
@@ -859,6 +922,12 @@ class FileWriter:
                 return addrs[0]
             nodes = [(g[0][0], g[0][1], a) for g, a in zip(groups, addrs)]
             level += 1
+
+    def open_chunked_dataset(self, name: str, shape, dtype, chunks, attrs: dict | None = None) -> "ChunkedDatasetStream":
+        """A chunked (unfiltered) dataset whose chunks arrive one at a time, in any order, while
+        other work goes on -- the per-batch slabs of a run's sample table, written while the next
+        batch is swept.  :meth:`ChunkedDatasetStream.close` writes the chunk index and the header."""
+        return ChunkedDatasetStream(self, name, shape, dtype, chunks, attrs)
 
     # ---- close: groups + superblock -------------------------------------------------------------
     def _write_group(self, path: str) -> tuple[int, int, int]:

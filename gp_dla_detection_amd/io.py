@@ -156,6 +156,15 @@ class _MatWriter:
         return self.w.create_dataset_streamed(name, tuple(matlab_shape)[::-1], a, column_blocks,
                                               attrs={"MATLAB_class": cls})
 
+    def open_chunked(self, name: str, matlab_shape, dtype, stored_chunks):
+        """A MATLAB array written chunk by chunk while it is being produced
+        (:meth:`hdf5.FileWriter.open_chunked_dataset`); ``stored_chunks``: chunk extents of the
+        STORED (dimension-reversed) array."""
+        a = np.dtype(dtype)
+        cls = "double" if a.kind == "f" and a.itemsize == 8 else self._class_of(np.zeros(0, a))
+        return self.w.open_chunked_dataset(name, tuple(matlab_shape)[::-1], a, stored_chunks,
+                                           attrs={"MATLAB_class": cls})
+
     def close(self):
         self.w.close()
 
@@ -418,6 +427,111 @@ def save_processed_qsos_multi(path: str, results: dict, test_ind=None, **run_met
             w.put(k, v.astype(np.uint32) if k == "base_sample_inds" else v.astype(np.float64))
     finally:
         w.close()
+
+
+class ProcessedStreamWriter:
+    """``save_processed_qsos`` / ``save_processed_qsos_multi`` for a run whose results arrive batch
+    by batch: the per-sample tables -- 1.6 GB for a DR12Q shard, the only large variables -- are
+    transposed into MATLAB's order and written as one column of HDF5 chunks per batch WHILE the next
+    batch is swept (:meth:`append`, called by the pipeline's download thread); :meth:`finish`
+    writes the per-quasar variables and the metadata.  The file holds the same variables with the
+    same shapes and classes as the one-shot writers'; the large ones are chunked (as MATLAB's own
+    ``-v7.3`` files are) instead of contiguous.  ``batch``: quasars per batch -- every batch but the
+    last must have exactly that many."""
+
+    _TARGET = 8 << 20  # bytes per chunk, about
+
+    def __init__(self, path: str, num_quasars: int, num_samples: int, batch: int, max_dlas: int = 0):
+        self.nq, self.S, self.B, self.md = int(num_quasars), int(num_samples), max(1, int(batch)), int(max_dlas)
+        self.w = _MatWriter(path)
+        self.done = 0
+        S, nq, B = self.S, self.nq, min(self.B, max(1, self.nq))
+        self.B = B
+
+        def rows(itemsize):  # chunk extent along the sample axis
+            return max(1, min(S, self._TARGET // (itemsize * B)))
+        self.streams = {}
+        try:
+            if self.md:  # stored (dimension-reversed): [md, S, nq], [md - 1, S, nq], [S, nq]
+                self.streams["sample_log_likelihoods_dla"] = (
+                    self.w.open_chunked("sample_log_likelihoods_dla", (nq, S, self.md), np.float64, (1, rows(8), B)), 8)
+                if self.md > 1:
+                    self.streams["base_sample_inds"] = (
+                        self.w.open_chunked("base_sample_inds", (nq, S, self.md - 1), np.uint32, (1, rows(4), B)), 4)
+                self.streams["sample_log_likelihoods_lls"] = (
+                    self.w.open_chunked("sample_log_likelihoods_lls", (nq, S), np.float64, (rows(8), B)), 8)
+            else:
+                self.streams["sample_log_likelihoods_dla"] = (
+                    self.w.open_chunked("sample_log_likelihoods_dla", (nq, S), np.float64, (rows(8), B)), 8)
+        except Exception:
+            self.w.close()
+            raise
+
+    @property
+    def streamed(self):
+        return tuple(self.streams)
+
+    def append(self, at: int, tables: dict) -> None:
+        """The rows ``at .. at + n`` of the run: ``tables[name]`` = this package's orientation,
+        [n, S] or [n, model, S]."""
+        n = None
+        for name, (st, _) in self.streams.items():
+            t = np.asarray(tables[name])
+            n = t.shape[0] if n is None else n
+            if at % self.B or t.shape[0] != n or (n != self.B and at + n != self.nq):
+                raise ValueError(f"batch [{at}, {at + n}) does not sit on the {self.B}-quasar chunk grid")
+            cs = st.chunks[-2]
+            if t.ndim == 2:
+                tt = np.ascontiguousarray(t.T)  # [S, n]
+                for r0 in range(0, self.S, cs):
+                    st.write_chunk((r0, at), tt[r0:r0 + cs])
+            else:
+                for mdl in range(t.shape[1]):
+                    tt = np.ascontiguousarray(t[:, mdl, :].T)
+                    for r0 in range(0, self.S, cs):
+                        st.write_chunk((mdl, r0, at), tt[None, r0:r0 + cs])
+        self.done += n or 0
+
+    def finish(self, results: dict, test_ind=None, **run_metadata) -> None:
+        """The remaining variables of ``results`` (all rows) and the metadata; closes the file."""
+        w = self.w
+        try:
+            if self.done != self.nq:
+                raise ValueError(f"{self.done} of {self.nq} quasars were appended")
+            for st, _ in self.streams.values():
+                st.close()
+            extra = ("k", "min_z_cut", "num_dla_samples", "normalization_min_lambda",
+                     "normalization_max_lambda") if self.md else ()
+            _metadata(w, results, run_metadata, extra=extra)
+            if test_ind is not None:
+                w.put("test_ind", np.asarray(test_ind, dtype=bool).reshape(-1, 1))
+            if self.md:
+                for k in SAVED_VARIABLES_MULTI + ("MAP_inds",):
+                    if k in self.streams:
+                        continue
+                    if k not in results:
+                        if k in ("MAP_inds", "base_sample_inds"):
+                            continue
+                        raise KeyError(f"results lack {k}")
+                    v = np.asarray(results[k])
+                    if k in _MULTI_TO_MATLAB:
+                        v = np.transpose(v, _MULTI_TO_MATLAB[k])
+                    w.put(k, v.astype(np.uint32) if k == "base_sample_inds" else v.astype(np.float64))
+            else:
+                for k in SAVED_VARIABLES:
+                    if k not in self.streams:
+                        w.put(k, np.asarray(results[k], dtype=np.float64))
+                for k in ("MAP_inds", "MAP_z_dlas", "MAP_log_nhis"):  # (see save_processed_qsos)
+                    if k in results and np.ndim(results[k]) == 1:
+                        w.put("single_" + k, np.asarray(results[k], dtype=np.float64))
+        finally:
+            w.close()
+
+    def abort(self) -> None:
+        try:
+            self.w.close()
+        except Exception:
+            pass
 
 
 def load_processed_qsos(path: str) -> dict:

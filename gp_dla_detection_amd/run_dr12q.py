@@ -15,7 +15,9 @@ ranks of one ``torch.distributed`` process group, one per GPU:
 4. each rank writes its own chunk ``processed_qsos_<name>_<lo>-<hi>.mat`` (single-DLA variables of
    process_qsos.m:236-250, or the multi-DLA list of multi :498-523) with the chunk's own
    ``test_ind`` -- a file the reference's ``mat_combine`` recombines unchanged
-   (tests/golden/make_consumer_fixtures.py does exactly that);
+   (tests/golden/make_consumer_fixtures.py does exactly that); the per-sample tables, the only
+   large variables, are written batch by batch while the next batch is swept
+   (:class:`io.ProcessedStreamWriter`: one column of HDF5 chunks per batch);
 5. the per-quasar posterior rows (15 or 78 fp64) are all-gathered over RCCL, so every rank -- and
    rank 0's ``*_summary.mat`` -- holds the whole run's posterior table; the per-sample tables stay
    in the chunks, as the reference keeps them per job.
@@ -64,9 +66,14 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
     ``prior_catalog``: ``{"z_qsos", "dla_ind"}`` of the training release (``api.prepare_prior``);
     multi-DLA runs also need ``Z_lls`` / ``Z_dla`` (set_lls_parameters.m:59-71).
     Returns ``dict(fields=<posterior variables of ALL quasars of the run>, block=(lo, hi),
-    chunk=<path of this rank's chunk file or None>, selected=<catalogue indices of the run>)``."""
+    chunk=<path of this rank's chunk file or None>, selected=<catalogue indices of the run>,
+    timings=<seconds: setup_s, pipeline_s, save_s, total_s>)``."""
+    import time
+
     import torch
 
+    t_start = time.perf_counter()
+    timings = {}
     world, rank = _world()
     p = params or (MultiParameters() if multi else Parameters())
     if device is None:
@@ -104,6 +111,7 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
         stream = torch.cuda.Stream(device=device)
         table = torch.empty((nloc, ncol), dtype=torch.float64, device=f"cuda:{device}")
         local = None
+        chunk = None
         if nloc:
             if max_quasars_per_batch is None:
                 max_quasars_per_batch = default_batch_size(nloc, int(counts[lo:hi].max()), k, S, pipeline_slots,
@@ -111,6 +119,10 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
             blocks = batch_blocks(nloc, max_quasars_per_batch)
             local = (Batch.empty_results_multi(nloc, p.max_dlas, S) if multi else Batch.empty_results(nloc, S))
             ctx = Context(device, p, stream=stream)
+            # the chunk file is open from the start: the download thread transposes each batch's
+            # per-sample tables into MATLAB's order and writes them while the next batch is swept
+            chunk = io.chunk_filename(out_dir, test_set_name, lo, hi, multi)
+            writer = io.ProcessedStreamWriter(chunk, nloc, S, blocks[0][1] - blocks[0][0], p.max_dlas if multi else 0)
 
             def inputs(i):  # runs on the upload thread: file reads overlap the sweep in flight
                 b0, b1 = blocks[i]
@@ -129,33 +141,39 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
                     table[b0:b1].copy_(batch.summary_tensor())
 
             def download(i, batch):
-                b0, _ = blocks[i]
+                b0, b1 = blocks[i]
                 (batch.download_multi(True, local, b0) if multi else batch.download(True, local, b0))
+                writer.append(b0, {k_: local[k_][b0:b1] for k_ in writer.streamed})
 
             try:
                 ctx.set_model(model)
                 ctx.set_samples(samples)
+                timings["setup_s"] = time.perf_counter() - t_start
                 run_pipeline(ctx, len(blocks), inputs, process, download, pipeline_slots,
                              warm=lambda: prefault(local["sample_log_likelihoods_dla"]))
                 stream.synchronize()
+                timings["pipeline_s"] = time.perf_counter() - t_start - timings["setup_s"]
+            except BaseException:
+                writer.abort()
+                if os.path.exists(chunk):
+                    os.remove(chunk)  # a partial chunk file must not be mistaken for a finished one
+                raise
             finally:
                 ctx.close()
     finally:
         reader.close()
+    t_save = time.perf_counter()
 
-    chunk = None
     if nloc:
-        chunk = io.chunk_filename(out_dir, test_set_name, lo, hi, multi)
         mask = np.zeros(z_all.size, dtype=bool)
         mask[sel[lo:hi]] = True
         meta = dict(test_set_name=test_set_name, **(run_metadata or {}))
         local.update(num_lines=p.num_lines, prior_z_qso_increase=p.prior_z_qso_increase, max_z_cut=p.max_z_cut)
         if multi:
             local.update(k=k, min_z_cut=p.min_z_cut, num_dla_samples=S)
-            io.save_processed_qsos_multi(chunk, local, test_ind=mask, **meta)
-        else:
-            io.save_processed_qsos(chunk, local, test_ind=mask, **meta)
+        writer.finish(local, test_ind=mask, **meta)
 
+    timings["save_s"] = time.perf_counter() - t_save
     with torch.cuda.stream(stream):
         gathered = gather_summaries(table, [b[1] - b[0] for b in bounds])
     stream.synchronize()
@@ -166,7 +184,8 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
         stem = f"processed_qsos_multi_meanflux{test_set_name}" if multi else f"processed_qsos_{test_set_name}"
         io.savemat73(os.path.join(out_dir, stem + "_summary.mat"),
                      dict(test_ind=mask.reshape(-1, 1), **{k_: v for k_, v in fields.items()}))
-    return dict(fields=fields, block=(lo, hi), chunk=chunk, selected=sel)
+    timings["total_s"] = time.perf_counter() - t_start
+    return dict(fields=fields, block=(lo, hi), chunk=chunk, selected=sel, timings=timings)
 
 
 def main(argv=None):

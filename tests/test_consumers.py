@@ -256,3 +256,45 @@ def test_libhdf5_reads_the_committed_chunk_files():
             else:
                 np.testing.assert_array_equal(raw.reshape(S, n).T, part["sample_log_likelihoods_dla"])
             os.remove(out)
+
+
+@needs_libhdf5
+def test_libhdf5_reads_the_streamed_chunk_writer(tmp_path):
+    """What a sharded run writes batch by batch (io.ProcessedStreamWriter: one column of unfiltered
+    HDF5 chunks per batch, ragged last batch, chunk index written at the end), read back by
+    libhdf5's h5dump / h5ls and equal to the one-shot writers' files variable for variable."""
+    from gp_dla_detection_amd.api import Batch
+    rng = np.random.default_rng(11)
+    nq, S_, B = 29, 70, 8
+    mask = np.zeros(40, bool)
+    mask[:nq] = True
+    for md in (0, 3):
+        res = Batch.empty_results_multi(nq, md, S_) if md else Batch.empty_results(nq, S_)
+        for k, v in res.items():
+            if isinstance(v, np.ndarray) and v.dtype == np.float64:
+                v[...] = rng.standard_normal(v.shape)
+            if isinstance(v, np.ndarray) and v.dtype == np.uint32:
+                v[...] = rng.integers(1, S_ + 1, v.shape)
+        res.update(num_lines=3, prior_z_qso_increase=0.1, max_z_cut=0.1, k=20, min_z_cut=0.1, num_dla_samples=S_)
+        one, streamed = str(tmp_path / f"one{md}.mat"), str(tmp_path / f"streamed{md}.mat")
+        (io.save_processed_qsos_multi if md else io.save_processed_qsos)(one, res, test_ind=mask, test_set_name="t")
+        w = io.ProcessedStreamWriter(streamed, nq, S_, B, max_dlas=md)
+        for at in range(0, nq, B):
+            w.append(at, {k: res[k][at:at + B] for k in w.streamed})
+        w.finish(res, test_ind=mask, test_set_name="t")
+        a, b = io.load_processed_qsos(one), io.load_processed_qsos(streamed)
+        assert sorted(a) == sorted(b)
+        for k in a:
+            x, y = np.asarray(a[k]), np.asarray(b[k])
+            assert x.shape == y.shape and x.dtype == y.dtype, k
+            assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), k
+        ls = subprocess.run([H5LS, "-v", streamed], check=True, capture_output=True, text=True).stdout
+        assert "Chunks:" in ls and (f"{{{S_}/{S_}, {nq}/{nq}}}" in ls)
+        raw = h5dump_binary(streamed, "/sample_log_likelihoods_dla", "<f8", str(tmp_path))
+        want = res["sample_log_likelihoods_dla"]
+        if md:
+            np.testing.assert_array_equal(raw.reshape(md, S_, nq).transpose(2, 0, 1), want)
+            np.testing.assert_array_equal(h5dump_binary(streamed, "/base_sample_inds", "<u4", str(tmp_path))
+                                          .reshape(md - 1, S_, nq).transpose(2, 0, 1), res["base_sample_inds"])
+        else:
+            np.testing.assert_array_equal(raw.reshape(S_, nq).T, want)

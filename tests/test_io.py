@@ -1,6 +1,7 @@
 """Round trips of the .mat readers/writers: v5 files through scipy, -v7.3 (HDF5) files through the
 package's own HDF5 implementation (tests/test_hdf5.py tests that layer by itself)."""
 import numpy as np
+import pytest
 from scipy.io import savemat
 
 from gp_dla_detection_amd import io, synthetic
@@ -141,3 +142,34 @@ def test_processed_qsos_multi_v73(tmp_path):
     back = io.load_processed_qsos(p)
     for k in ("sample_log_likelihoods_dla", "base_sample_inds", "MAP_inds", "log_likelihoods_dla", "all_exceptions"):
         np.testing.assert_array_equal(back[k], res[k])
+
+
+def test_chunked_dataset_stream(tmp_path):
+    """hdf5.FileWriter.open_chunked_dataset: chunks written in any order between other datasets,
+    ragged edges zero-filled, index and header written by close(); misuse is refused."""
+    from gp_dla_detection_amd import hdf5
+    a = np.arange(23 * 37, dtype=np.float64).reshape(23, 37)
+    p = str(tmp_path / "c.h5")
+    w = hdf5.FileWriter(p)
+    st = w.open_chunked_dataset("x", a.shape, np.float64, (5, 8))
+    offs = [(i, j) for i in range(0, 23, 5) for j in range(0, 37, 8)]
+    np.random.default_rng(1).shuffle(offs)
+    for n, (i, j) in enumerate(offs):
+        st.write_chunk((i, j), a[i:i + 5, j:j + 8])
+        if n == 3:
+            w.create_dataset("y", np.arange(5.0))
+    with pytest.raises(hdf5.HDF5Error):
+        st.write_chunk((0, 0), a[:5, :8])      # twice
+    with pytest.raises(hdf5.HDF5Error):
+        st.write_chunk((1, 0), a[:5, :8])      # off the grid
+    st.close()
+    w.close()
+    with hdf5.File(p) as f:
+        np.testing.assert_array_equal(f["x"].read(), a)
+        np.testing.assert_array_equal(f["y"].read(), np.arange(5.0))
+    w = hdf5.FileWriter(str(tmp_path / "d.h5"))
+    st = w.open_chunked_dataset("x", (4, 4), np.float64, (2, 2))
+    st.write_chunk((0, 0), np.zeros((2, 2)))
+    with pytest.raises(hdf5.HDF5Error):
+        st.close()                              # three chunks missing
+    w.close()

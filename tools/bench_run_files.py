@@ -29,4 +29,4 @@ t_run = time.perf_counter() - t0
 size = os.path.getsize(res["chunk"])
 print(json.dumps(dict(quasars=nq, samples=S, seconds=t_run, evals_per_s=nq * S / t_run, quasars_per_s=nq / t_run,
                       chunk_bytes=size, input_bytes=os.path.getsize(fs["paths"]["preloaded"]),
-                      generate_inputs_s=t_gen, finite_p_dlas=int(np.isfinite(res["fields"]["p_dlas"]).sum()))))
+                      generate_inputs_s=t_gen, timings=res["timings"], finite_p_dlas=int(np.isfinite(res["fields"]["p_dlas"]).sum()))))
