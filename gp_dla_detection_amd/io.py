@@ -23,6 +23,7 @@ multi-DLA: [num_quasars x S x max_dlas]) unless stated otherwise.
 from __future__ import annotations
 
 import datetime
+import os
 
 import numpy as np
 
@@ -275,6 +276,44 @@ def load_preloaded_qsos(path: str, z_qsos, test_ind=None) -> list:
                  z_qso=float(z[i])) for j, i in enumerate(idx)]
 
 
+# ---------------------------------------------------------------------------------------------
+# native cell reader (csrc/h5cells.c): the cells of a -v7.3 cell array, many at a time, in threads
+# ---------------------------------------------------------------------------------------------
+
+_H5CELLS_SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "h5cells.c")
+_H5CELLS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgpdla_h5cells.so")
+_h5cells = None
+
+
+def build_h5cells(force: bool = False) -> str:
+    """gcc -O2 -fopenmp csrc/h5cells.c -lz -> csrc/libgpdla_h5cells.so (host code: no GPU involved)."""
+    import subprocess
+    if force or not os.path.exists(_H5CELLS_LIB) or os.path.getmtime(_H5CELLS_LIB) < os.path.getmtime(_H5CELLS_SRC):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-Wall", _H5CELLS_SRC, "-lz",
+                               "-o", _H5CELLS_LIB])
+    return _H5CELLS_LIB
+
+
+def _load_h5cells():
+    """The native cell reader, or None when it cannot be built / loaded (no gcc or zlib on the box):
+    :class:`PreloadedReader` then reads every cell with the Python reader -- same arrays, slower."""
+    global _h5cells
+    if _h5cells is None:
+        import ctypes as C
+        try:
+            lib = C.CDLL(build_h5cells())
+            lib.gpdla_h5cells_sizes.restype = C.c_int
+            lib.gpdla_h5cells_sizes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p,
+                                                C.c_void_p, C.c_int]
+            lib.gpdla_h5cells_read.restype = C.c_int64
+            lib.gpdla_h5cells_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            _h5cells = lib
+        except Exception:  # (a missing compiler must not stop a run: the Python reader is complete)
+            _h5cells = False
+    return _h5cells or None
+
+
 class PreloadedReader:
     """Random access to the ragged cell arrays of a ``-v7.3`` preloaded_qsos.mat (preload_qsos.m:64-79):
     the file is opened once, the four reference tables are read, and a rank then dereferences only
@@ -283,9 +322,14 @@ class PreloadedReader:
     one thread): ~8800 quasars/s for contiguous cells, ~3300/s for deflate-compressed ones as MATLAB
     writes them (30 % of that is zlib, the rest header parsing under the GIL, so threads do not
     help): a DR12Q shard of 20 358 quasars is ~6 s of reading next to 1.9 s of sweep -- hidden behind
-    the sweep only in part (run_dr12q reads batch i + 1 while batch i is swept)."""
+    the sweep only in part (run_dr12q reads batch i + 1 while batch i is swept).
+    :meth:`read_csr` is the fast path: the same cells through csrc/h5cells.c (object headers, chunk
+    B-trees and zlib in C, cells spread over threads), straight into the flat arrays a batch
+    upload takes; cells outside that reader's subset, or a box without gcc, fall back to the
+    Python reader cell by cell."""
 
     KEYS = ("all_wavelengths", "all_flux", "all_noise_variance", "all_pixel_mask")
+    _DTYPES = (np.float64, np.float64, np.float64, np.uint8)
 
     def __init__(self, path: str):
         if not _is_hdf5(path):
@@ -299,12 +343,76 @@ class PreloadedReader:
                 raise KeyError(f"{path} lacks {k}")
             self._refs[k] = self._f[k].read().T.ravel(order="F")
         self.num_quasars = int(self._refs[self.KEYS[0]].size)
+        self._map = None  # (address, length) of the file's memory map, for the native reader
+        self.threads = max(1, min(16, len(os.sched_getaffinity(0))))
+
+    def _native(self):
+        lib = _load_h5cells()
+        if lib is not None and self._map is None:
+            view = np.frombuffer(self._f._mm, dtype=np.uint8)  # the map hdf5.File already holds
+            self._map = (view.ctypes.data, view.size, view)
+        return lib
+
+    def _python_count(self, i) -> int:
+        ds = self._f.dereference(self._refs["all_wavelengths"][i])
+        if len(ds.shape) == 1 and "MATLAB_empty" in ds.attrs:
+            return 0
+        return int(np.prod(ds.shape))
 
     def pixel_counts(self, indices=None) -> np.ndarray:
         """Stored pixels per quasar (``numel(all_wavelengths{i})``) for the 0-based ``indices``."""
         idx = np.arange(self.num_quasars) if indices is None else np.asarray(indices)
-        refs = self._refs["all_wavelengths"]
-        return np.array([int(np.prod(self._f.dereference(refs[i]).shape)) for i in idx], dtype=np.int64)
+        lib = self._native()
+        if lib is None or idx.size == 0:
+            return np.array([self._python_count(i) for i in idx], dtype=np.int64)
+        addrs = np.ascontiguousarray(self._refs["all_wavelengths"][idx], dtype=np.uint64)
+        counts = np.empty(idx.size, dtype=np.int64)
+        sizes = np.empty(idx.size, dtype=np.int32)
+        lib.gpdla_h5cells_sizes(self._map[0], self._map[1], self._f.userblock_size, addrs.ctypes.data, idx.size, counts.ctypes.data,
+                                sizes.ctypes.data, self.threads)
+        for j in np.flatnonzero(counts < 0):  # outside the native reader's subset (e.g. an empty cell)
+            counts[j] = self._python_count(idx[j])
+        return counts
+
+    def read_csr(self, indices, z_qsos) -> dict:
+        """The spectra of the 0-based ``indices`` as the flat arrays a batch upload takes
+        (``api.spectra_to_csr``'s dict: offsets, wavelengths, flux, noise_variance, pixel_mask,
+        z_qsos), read by the native reader where it applies."""
+        z = _vec(z_qsos)
+        if z.size != self.num_quasars:
+            raise ValueError(f"{self.num_quasars} spectra but {z.size} redshifts")
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        counts = self.pixel_counts(idx)
+        offsets = np.zeros(idx.size + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        total = int(offsets[-1])
+        out = dict(offsets=offsets, z_qsos=np.ascontiguousarray(z[idx], dtype=np.float64))
+        lib = self._native()
+        for key, dt, name in zip(self.KEYS, self._DTYPES, ("wavelengths", "flux", "noise_variance", "pixel_mask")):
+            flat = np.empty(total, dtype=dt)
+            status = np.full(idx.size, -1, dtype=np.int8)
+            if lib is not None and idx.size:
+                addrs = np.ascontiguousarray(self._refs[key][idx], dtype=np.uint64)
+                byte_off = np.ascontiguousarray(offsets[:-1] * flat.itemsize)
+                lib.gpdla_h5cells_read(self._map[0], self._map[1], self._f.userblock_size, addrs.ctypes.data, idx.size, flat.itemsize,
+                                       flat.ctypes.data, byte_off.ctypes.data, counts.ctypes.data, status.ctypes.data,
+                                       self.threads)
+            for j in np.flatnonzero(status):  # the Python reader, for whatever the native one left
+                v = self._vec(key, idx[j], dt)
+                if v.size != counts[j]:
+                    raise ValueError(f"{self.path}: {key}{{{idx[j] + 1}}} has {v.size} elements, "
+                                     f"all_wavelengths{{{idx[j] + 1}}} {counts[j]}")
+                flat[offsets[j]:offsets[j + 1]] = v
+            out[name] = flat
+        return out
+
+    def _vec(self, key, i, dt):
+        # the cells are plain numeric / logical vectors: their class attributes are not needed,
+        # only an empty cell (stored as its dimensions, MATLAB_empty) must be told apart
+        ds = self._f.dereference(self._refs[key][i])
+        if len(ds.shape) == 1 and "MATLAB_empty" in ds.attrs:
+            return np.zeros(0, dtype=dt)
+        return np.asarray(ds.read(), dtype=dt).reshape(-1)
 
     def read(self, indices, z_qsos) -> list:
         """Per-quasar dicts (as :func:`load_preloaded_qsos` returns) for the 0-based ``indices``;
@@ -312,15 +420,7 @@ class PreloadedReader:
         z = _vec(z_qsos)
         if z.size != self.num_quasars:
             raise ValueError(f"{self.num_quasars} spectra but {z.size} redshifts")
-        f, refs = self._f, self._refs
-
-        def vec(key, i, dt):
-            # the cells are plain numeric / logical vectors: their class attributes are not needed,
-            # only an empty cell (stored as its dimensions, MATLAB_empty) must be told apart
-            ds = f.dereference(refs[key][i])
-            if len(ds.shape) == 1 and "MATLAB_empty" in ds.attrs:
-                return np.zeros(0, dtype=dt)
-            return np.asarray(ds.read(), dtype=dt).reshape(-1)
+        vec = self._vec
 
         return [dict(wavelengths=vec("all_wavelengths", i, np.float64), flux=vec("all_flux", i, np.float64),
                      noise_variance=vec("all_noise_variance", i, np.float64),
@@ -328,6 +428,7 @@ class PreloadedReader:
                 for i in np.asarray(indices)]
 
     def close(self):
+        self._map = None  # (drops the view of the map before hdf5.File closes it)
         self._f.close()
 
     def __enter__(self):

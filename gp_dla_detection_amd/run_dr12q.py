@@ -126,7 +126,7 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
 
             def inputs(i):  # runs on the upload thread: file reads overlap the sweep in flight
                 b0, b1 = blocks[i]
-                spectra = reader.read(sel[lo + b0:lo + b1], z_all)
+                spectra = reader.read_csr(sel[lo + b0:lo + b1], z_all)  # flat arrays, native reader (csrc/h5cells.c)
                 args = (spectra, lp_no[b0:b1], lp_dla[b0:b1])
                 return args + ((lp_lls[b0:b1],) if multi else ())
 

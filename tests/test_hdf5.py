@@ -283,3 +283,25 @@ def test_random_round_trips_hypothesis(tmp_path_factory):
             assert f.eof == os.path.getsize(p)
 
     run()
+
+
+@pytest.mark.skipif(not (MATLAB_FILE and os.path.exists(MATLAB_FILE)), reason="SciPy's MATLAB -v7.3 sample absent")
+def test_native_cell_reader_on_a_file_written_by_matlab():
+    """csrc/h5cells.c on bytes MATLAB wrote (version-1 object header, version-2 contiguous layout)."""
+    lib = io._load_h5cells()
+    if lib is None:
+        pytest.skip("no gcc / zlib on this box: the native cell reader is not built")
+    with hdf5.File(MATLAB_FILE) as f:
+        view = np.frombuffer(f._mm, dtype=np.uint8)
+        addrs = np.array([f["testdouble"].addr], dtype=np.uint64)
+        counts, sizes = np.empty(1, np.int64), np.empty(1, np.int32)
+        lib.gpdla_h5cells_sizes(view.ctypes.data, view.size, f.userblock_size, addrs.ctypes.data, 1,
+                                counts.ctypes.data, sizes.ctypes.data, 1)
+        assert counts[0] == 9 and sizes[0] == 8
+        out, status = np.empty(9), np.full(1, -1, np.int8)
+        off = np.zeros(1, np.int64)
+        failed = lib.gpdla_h5cells_read(view.ctypes.data, view.size, f.userblock_size, addrs.ctypes.data, 1, 8,
+                                        out.ctypes.data, off.ctypes.data, counts.ctypes.data, status.ctypes.data, 1)
+        assert failed == 0 and status[0] == 0
+        np.testing.assert_array_equal(out, f["testdouble"].read().ravel())
+        del view

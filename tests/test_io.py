@@ -173,3 +173,38 @@ def test_chunked_dataset_stream(tmp_path):
     with pytest.raises(hdf5.HDF5Error):
         st.close()                              # three chunks missing
     w.close()
+
+
+def test_native_cell_reader_equals_the_python_reader(tmp_path, monkeypatch):
+    """PreloadedReader.read_csr (csrc/h5cells.c: object headers, chunk B-trees, zlib, threads) against
+    the pure-Python reader: deflate-compressed cells as MATLAB writes them, contiguous cells, an
+    empty cell and a non-vector cell (both outside the native subset: Python fallback), any index
+    order; and the whole thing again with the native library unavailable."""
+    from gp_dla_detection_amd import api
+    rng = np.random.default_rng(2)
+    n = 37
+    lens = rng.integers(1, 1500, n)   # >= 512 doubles: written chunked + deflate when compress=True
+    lens[5] = 0                       # an empty cell (MATLAB_empty: rank-1 dimension list)
+    lens[9] = 150000                  # several 1 MiB chunks behind one B-tree node
+    cells = {k: [rng.standard_normal((m, 1)) for m in lens] for k in ("all_wavelengths", "all_flux", "all_noise_variance")}
+    cells["all_flux"][3][::7] = np.nan
+    cells["all_pixel_mask"] = [rng.uniform(size=(m, 1)) < 0.2 for m in lens]
+    z = rng.uniform(2, 5, n)
+    idx = np.concatenate([[5, 9], rng.permutation(n)[:27]])
+    for compress in (True, False):
+        p = str(tmp_path / f"pre{int(compress)}.mat")
+        io.savemat73(p, cells, compress=compress)
+        for native in (True, False):
+            if not native:
+                monkeypatch.setattr(io, "_h5cells", False)
+            with io.PreloadedReader(p) as r:
+                assert (r._native() is not None) == native
+                want = api.spectra_to_csr(r.read(idx, z))
+                got = r.read_csr(idx, z)
+                np.testing.assert_array_equal(r.pixel_counts(idx), lens[idx])
+            assert sorted(got) == sorted(want)
+            for k in want:
+                a, b = np.asarray(want[k]), np.asarray(got[k])
+                assert a.dtype == b.dtype and a.shape == b.shape, k
+                np.testing.assert_array_equal(a, b, err_msg=k)
+            monkeypatch.setattr(io, "_h5cells", None)
