@@ -15,19 +15,21 @@ from gp_dla_detection_amd import run_dr12q, synthetic  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else None  # quasars per HBM-resident batch (default: run_dr12q's)
+batch = (int(sys.argv[3]) or None) if len(sys.argv) > 3 else None  # quasars per HBM-resident batch (0 / absent: run_dr12q's)
+multi = len(sys.argv) > 4 and sys.argv[4] == "multi"
+mk = dict(multi=True, Z_lls=0.31, Z_dla=0.69) if multi else {}
 d = tempfile.mkdtemp(prefix="gpdla_files_")
 t0 = time.perf_counter()
 fs = synthetic.write_file_set(d, num_quasars=nq, num_samples=S, skip_every=10 ** 9, empty_quasar=None)
 t_gen = time.perf_counter() - t0
 pr = fs["prior"]
 run_dr12q.run(fs["paths"]["preloaded"], fs["paths"]["catalog"], fs["paths"]["learned"], fs["paths"]["samples"],
-              d + "/warm", "warm", test_ind=np.arange(64), prior_catalog=pr, device=0)  # warm-up
+              d + "/warm", "warm", test_ind=np.arange(64), prior_catalog=pr, device=0, **mk)  # warm-up
 t0 = time.perf_counter()
 res = run_dr12q.run(fs["paths"]["preloaded"], fs["paths"]["catalog"], fs["paths"]["learned"], fs["paths"]["samples"],
-                    d + "/out", "synth", prior_catalog=pr, device=0, max_quasars_per_batch=batch)
+                    d + "/out", "synth", prior_catalog=pr, device=0, max_quasars_per_batch=batch, **mk)
 t_run = time.perf_counter() - t0
 size = os.path.getsize(res["chunk"])
-print(json.dumps(dict(quasars=nq, samples=S, seconds=t_run, evals_per_s=nq * S / t_run, quasars_per_s=nq / t_run,
+print(json.dumps(dict(quasars=nq, samples=S, multi=multi, seconds=t_run, evals_per_s=nq * S * (5 if multi else 1) / t_run, quasars_per_s=nq / t_run,
                       chunk_bytes=size, input_bytes=os.path.getsize(fs["paths"]["preloaded"]),
                       generate_inputs_s=t_gen, batch=batch, timings=res["timings"], finite_p_dlas=int(np.isfinite(res["fields"]["p_dlas"]).sum()))))
