@@ -167,6 +167,17 @@ def test_chunked_dataset_stream(tmp_path):
     with hdf5.File(p) as f:
         np.testing.assert_array_equal(f["x"].read(), a)
         np.testing.assert_array_equal(f["y"].read(), np.arange(5.0))
+    # more chunks than one index node holds (64): a two-level B-tree, chunks arriving column-major
+    b = np.random.default_rng(0).standard_normal((97, 211))
+    w = hdf5.FileWriter(str(tmp_path / "e.h5"))
+    st = w.open_chunked_dataset("x", b.shape, np.float64, (4, 3))
+    for j in range(0, 211, 3):
+        for i in range(0, 97, 4):
+            st.write_chunk((i, j), b[i:i + 4, j:j + 3])
+    st.close()
+    w.close()
+    with hdf5.File(str(tmp_path / "e.h5")) as f:
+        np.testing.assert_array_equal(f["x"].read(), b)
     w = hdf5.FileWriter(str(tmp_path / "d.h5"))
     st = w.open_chunked_dataset("x", (4, 4), np.float64, (2, 2))
     st.write_chunk((0, 0), np.zeros((2, 2)))
