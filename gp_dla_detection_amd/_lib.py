@@ -129,6 +129,7 @@ SYMBOLS = [
     ("gpdla_training_create", C.c_int, [C.c_int, C.c_int64, C.c_int64, _dp, _dp, _dp,
                                         C.POINTER(C.c_void_p)]),
     ("gpdla_training_objective", C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
+    ("gpdla_training_set_lyseries", C.c_int, [C.c_void_p, C.c_int, _dp, _dp]),
     ("gpdla_training_destroy", None, [C.c_void_p]),
     ("gpdla_debug_near_poly", C.c_int, [C.c_int, C.c_double, _dp, _dp]),
     ("gpdla_debug_prepared_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _dp, C.c_int64, _i64p]),

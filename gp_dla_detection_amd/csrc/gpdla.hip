@@ -1495,6 +1495,9 @@ void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uin
 struct gpdla_training {
   int device_id = 0;
   int64_t nq = 0, G = 0, ld = 0;  // ld: row stride of the training arrays (G rounded up to 16)
+  // mean-flux model's objective (gpdla_training_set_lyseries): lines.nfl > 1, d_nl = active lines per pixel
+  TrainLines lines{};
+  uint8_t *d_nl = nullptr;
   double *d_flux = nullptr, *d_lya = nullptr, *d_noise = nullptr, *d_loglya = nullptr;
   double *d_x = nullptr, *d_g = nullptr, *d_omega2 = nullptr, *d_f = nullptr;
   int32_t *d_flag = nullptr;
@@ -1555,7 +1558,8 @@ void gpdla_training_destroy(gpdla_training *t) {
   (void)hipDeviceSynchronize();
   training_free_workspace(t);  // graph, then stream, then the buffers the graph pointed at
   for (void *p : {(void *)t->d_flux, (void *)t->d_lya, (void *)t->d_noise, (void *)t->d_x, (void *)t->d_g,
-                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag, (void *)t->d_loglya, (void *)t->d_slots})
+                  (void *)t->d_omega2, (void *)t->d_f, (void *)t->d_flag, (void *)t->d_loglya, (void *)t->d_slots,
+                  (void *)t->d_nl})
     dev_free(p);
   if (t->h_stage) (void)hipHostFree(t->h_stage);
   delete t;
@@ -1656,6 +1660,8 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   ba.noise = t->d_noise;
   ba.omega2 = t->d_omega2;
   ba.x = t->d_x;
+  ba.nl = t->d_nl;
+  ba.lines = t->lines;
   ba.Brec = t->d_recM;
   ba.groups = K::Groups;
   ba.w_tiles = K::W;
@@ -1682,6 +1688,8 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   co.log_lya_1pz = t->d_loglya;
   co.noise = t->d_noise;
   co.x = t->d_x;
+  co.nl = t->d_nl;
+  co.lines = t->lines;
   co.wB = t->d_wB;
   co.uB = t->d_uB;
   co.partcol = t->d_partcol;
@@ -1815,6 +1823,61 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
 
 extern "C" {
 
+int gpdla_training_set_lyseries(gpdla_training *t, int num_forest_lines, const double *all_transition_wavelengths,
+                                const double *all_oscillator_strengths) {
+  if (!t) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null training set");
+  if (num_forest_lines < 0 || num_forest_lines > kTrMaxLines)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "num_forest_lines = %d outside [0, %d]", num_forest_lines, kTrMaxLines);
+  HIP_TRY(hipSetDevice(t->device_id));
+  training_drop_graph(t);  // the captured kernel arguments carry the line table
+  TrainLines L{};
+  if (num_forest_lines <= 1) {  // back to objective.m / spectrum_loss.m
+    t->lines = L;
+    return GPDLA_OK;
+  }
+  const double *wl = all_transition_wavelengths, *fs = all_oscillator_strengths;
+  // default: the Lyman series of voigt.c:20-182 (include/gpdla_lyman_series.h) = set_parameters_multi.m:76-143,
+  // wavelengths in Angstrom
+#define GPDLA_LINE_WL(i, wl_cm, f, rate, lead, width) wl_cm * 1e8,
+#define GPDLA_LINE_FS(i, wl_cm, f, rate, lead, width) f,
+  static const double wl_default[] = {GPDLA_LYMAN_SERIES(GPDLA_LINE_WL)};
+  static const double fs_default[] = {GPDLA_LYMAN_SERIES(GPDLA_LINE_FS)};
+#undef GPDLA_LINE_WL
+#undef GPDLA_LINE_FS
+  static_assert(sizeof wl_default / sizeof wl_default[0] == kTrMaxLines, "31 Lyman lines");
+  if (!wl || !fs) {
+    wl = wl_default;
+    fs = fs_default;
+  }
+  for (int l = 0; l < num_forest_lines; ++l) {
+    if (!(wl[l] > 0.0) || !(fs[l] > 0.0) || (l && !(wl[l] < wl[l - 1])))
+      return fail(GPDLA_ERR_INVALID_ARGUMENT, "line %d: wavelengths must be positive and decreasing, strengths positive", l + 1);
+    L.coef[l] = wl[l] * fs[l] / (wl[0] * fs[0]);  // spectrum_loss_lyseries.m:34-35
+    L.logr[l] = std::log(wl[0] / wl[l]);
+  }
+  L.nfl = num_forest_lines;
+  int rc;
+  if (!t->d_nl && (rc = dev_alloc(&t->d_nl, (size_t)t->nq * t->ld))) return rc;
+  HIP_TRY(hipMemset(t->d_flag, 0, sizeof(int32_t)));
+  TrainLinesArgs la;
+  la.nq = t->nq;
+  la.G = t->G;
+  la.ld = t->ld;
+  la.nfl = num_forest_lines;
+  for (int l = 0; l < kTrMaxLines; ++l) la.wl[l] = l < num_forest_lines ? wl[l] : 1.0;
+  la.lya_1pz = t->d_lya;
+  la.nl = t->d_nl;
+  la.not_prefix = t->d_flag;
+  const int64_t n = t->nq * t->ld;
+  hipLaunchKernelGGL(k_train_lines, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, la);
+  HIP_TRY(hipGetLastError());
+  int32_t bad = 0;
+  HIP_TRY(hipMemcpy(&bad, t->d_flag, sizeof bad, hipMemcpyDeviceToHost));
+  if (bad) return fail(GPDLA_ERR_UNSUPPORTED, "the active Lyman lines of some pixel are not a prefix of the series");
+  t->lines = L;
+  return GPDLA_OK;
+}
+
 int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *f, double *g) {
   if (!t || !x || !f || !g) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (k < 1 || k > GPDLA_MAX_K) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, GPDLA_MAX_K);
@@ -1841,6 +1904,7 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
   static const bool legacy = std::getenv("GPDLA_TRAIN_LEGACY") != nullptr;
   std::memcpy(t->h_stage, x, (size_t)nx * sizeof(double));
   if (!legacy) return training_objective_mfma(t, k, f, g);
+  if (t->lines.nfl > 1) return fail(GPDLA_ERR_UNSUPPORTED, "GPDLA_TRAIN_LEGACY has no Lyman-series objective");
   const int num_slots = (int)std::min<int64_t>(t->nq, 512);
   const int64_t slot_n = nx + 1;  // [g | f]
   if ((int64_t)num_slots * slot_n > t->slots_capacity) {

@@ -96,8 +96,63 @@ __device__ __forceinline__ double train_omega2(const double *x, int64_t G, int k
   return exp(2 * x[G * k + p]);  // objective.m:29
 }
 
+// The mean-flux model's objective (multi_dlas/objective_lyseries.m over spectrum_loss_lyseries.m)
+// differs from objective.m / spectrum_loss.m in ONE line: the optical depth of a pixel sums
+// num_forest_lines Lyman lines, tau_l (lambda_1 (1+z) / lambda_l)^beta with tau_l = tau_0 lambda_l f_l /
+// (lambda_1 f_1), each counted only where its redshift does not exceed the quasar's
+// (spectrum_loss_lyseries.m:22-39).  Lines are sorted by decreasing wavelength, so the active lines
+// of a pixel are a prefix 1..n, n = nl[q][p] (k_train_lines, the as-written comparison), and
+//   optical depth = (1+z)^beta * T[n],  T[n] = tau_0 Sum_{l <= n} coef_l exp(beta logr_l)
+// -- a table of nfl + 1 numbers per evaluation (T[1] = tau_0: the plain objective is nfl = 1).
+constexpr int kTrMaxLines = 31;
+struct TrainLines {
+  int32_t nfl;             // 0 / 1: spectrum_loss.m; > 1: spectrum_loss_lyseries.m
+  double coef[kTrMaxLines];  // lambda_l f_l / (lambda_1 f_1)
+  double logr[kTrMaxLines];  // log(lambda_1 / lambda_l)
+};
+// one thread fills T[0 .. nfl] (LDS); the caller's next barrier publishes it
+__device__ __forceinline__ void train_line_table(const TrainLines &L, double tau_0, double beta, double *T) {
+  double acc = 0.0;
+  T[0] = 0.0;
+  for (int l = 0; l < L.nfl; ++l) {
+    acc += tau_0 * L.coef[l] * exp(beta * L.logr[l]);
+    T[l + 1] = acc;
+  }
+}
+
+// k_train_lines: nl[q][p] = number of active lines of pixel p of quasar q, by the comparison of
+// spectrum_loss_lyseries.m:28-31 as written (zqso_1pz = the quasar's last lya_1pz,
+// objective_lyseries.m:46); *not_prefix is raised if the active lines are not 1..n somewhere.
+struct TrainLinesArgs {
+  int64_t nq, G, ld;
+  int32_t nfl;
+  double wl[kTrMaxLines];
+  const double *lya_1pz;  // [nq][ld]
+  uint8_t *nl;            // [nq][ld]
+  int32_t *not_prefix;
+};
+__global__ void k_train_lines(TrainLinesArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.nq * a.ld) return;
+  const int64_t q = e / a.ld, p = e - q * a.ld;
+  int n = 1;
+  if (p < a.G) {
+    const double zqso_1pz = a.lya_1pz[q * a.ld + a.G - 1], lya = a.lya_1pz[e];
+    bool open = true;
+    for (int l = 1; l < a.nfl; ++l) {
+      const double lyman_1pz = a.wl[0] * lya / a.wl[l];
+      const bool on = lyman_1pz <= zqso_1pz;
+      if (on && !open) *a.not_prefix = 1;
+      if (on && open) n = l + 1;
+      open = open && on;
+    }
+  }
+  a.nl[e] = (uint8_t)n;
+}
+
 // (log(1+z) is data: it is taken once, when the training set is uploaded, so that the power of
 // spectrum_loss.m:22 costs one exp per evaluation instead of a pow)
+// (tau_0: the pixel's line scale T[n] -- tau_0 itself for the plain objective)
 __device__ __forceinline__ void train_element(double y, double logz1, double nu, double om, double c_0,
                                               double tau_0, double beta, double *w, double *u, double *d_out) {
   const double od = tau_0 * fast_rcp(exp_nonpos(-beta * logz1));  // spectrum_loss.m:22: tau0 (1+z)^beta
@@ -187,7 +242,7 @@ constexpr int kTrChunk = 4;                             // steps per staged chun
 constexpr int kTrCWaves = 4;                            // row groups (waves) per block
 constexpr size_t kTrContractLds = 2 * kTrChunk * kTrGroupD * sizeof(double);  // 64 KiB
 constexpr int kTrBuildMaxChunks = 64;  // chunks of one split of k_train_build (its omega2 table: 8 KiB)
-constexpr size_t kTrBuildLds = kTrContractLds + 16 * kTrBuildMaxChunks * sizeof(double);
+constexpr size_t kTrBuildLds = kTrContractLds + (16 * kTrBuildMaxChunks + kTrMaxLines + 1) * sizeof(double);  // + the line table
 
 // NW: tiles of the block's group that take a_w (compile-time: the A operand of every MFMA is then
 // a fixed register, not a select)
@@ -301,6 +356,8 @@ struct TrainBuildArgs {
   const double *flux, *log_lya_1pz, *noise;  // [nq][ld], NaN flux = missing pixel (objective.m:42)
   const double *omega2;                      // [16 PG]
   const double *x;                           // the parameter vector
+  const uint8_t *nl;                         // [nq][ld] active lines per pixel (lines.nfl > 1 only)
+  TrainLines lines;
   const double *Brec;                        // recM
   int32_t groups, w_tiles, cols;
   int64_t group_stride;
@@ -335,17 +392,23 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
     glds_chunk<kTrChunk * kTrGroupD / 128, kTrCWaves>(brec + (c0 + c) * kTrChunk * kTrGroupD,
                                                       smem_lds + (uint32_t)(c & 1) * (uint32_t)(kTrChunk * kTrGroupD * 8), wave_s, lane);
   };
-  // omega2 of the split's pixels: once per block, behind the two record buffers
+  // omega2 of the split's pixels: once per block, behind the two record buffers; then the line table
   double *om_s = smem + 2 * kTrChunk * kTrGroupD;
   for (int e = threadIdx.x; e < 16 * nchunks; e += kTrCWaves * 64) om_s[e] = a.omega2[16 * c0 + e];
+  const bool lyseries = a.lines.nfl > 1;  // block-uniform
+  double *T_s = om_s + 16 * kTrBuildMaxChunks;
+  if (lyseries && threadIdx.x == 0) train_line_table(a.lines, sc.tau_0, sc.beta, T_s);
+  const uint32_t *pl = reinterpret_cast<const uint32_t *>(a.nl + (lyseries ? row : 0));
   // The raw elements are NOT double-buffered (the registers are needed for two waves per SIMD):
   // the first two pixels of the next chunk are requested when this chunk's second element has been
   // used, the last two after its fourth -- two to three K-steps ahead of their use.
   double2 f01, z01, n01, f23, z23, n23;
+  uint32_t nl4 = 0x01010101u;  // the four pixels' active-line counts
   auto load01 = [&](int c) {
     f01 = pf[(int64_t)c * 8];
     z01 = pz[(int64_t)c * 8];
     n01 = pn[(int64_t)c * 8];
+    if (lyseries) nl4 = pl[(int64_t)c * 4];
   };
   auto load23 = [&](int c) {
     f23 = pf[(int64_t)c * 8 + 1];
@@ -359,10 +422,10 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
   }
   double mant = 1.0, yy = 0.0, cnt = 0.0;
   int esum = 0;
-  auto element = [&](double y, double lz, double nv, double om, double &w, double &u) {
+  auto element = [&](double y, double lz, double nv, double om, uint32_t n_lines, double &w, double &u) {
     const bool ok = qreal && !isnan(y);  // rows behind the last quasar and padded / missing pixels
     double d;
-    train_element(y, lz, nv, om, sc.c_0, sc.tau_0, sc.beta, &w, &u, &d);
+    train_element(y, lz, nv, om, sc.c_0, lyseries ? T_s[n_lines] : sc.tau_0, sc.beta, &w, &u, &d);
     w = ok ? w : 0.0;
     u = ok ? u : 0.0;
     yy += ok ? y * u : 0.0;
@@ -381,15 +444,16 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
     const double *buf = smem + (size_t)(c & 1) * kTrChunk * kTrGroupD + lane;
     const double *omc = om_s + 16 * c + 4 * jj;
     const bool more = c + 1 < nchunks;
+    const uint32_t nl_cur = nl4;  // (the next chunk's counts arrive with its first two pixels)
     // element e is turned into (w, u) right in front of step e's MFMAs (the scheduling barriers keep
     // the four elements' temporaries from being live together)
 #pragma unroll
     for (int e = 0; e < kTrChunk; ++e) {
       double w, u;
-      if (e == 0) element(f01.x, z01.x, n01.x, omc[0], w, u);
-      if (e == 1) element(f01.y, z01.y, n01.y, omc[1], w, u);
-      if (e == 2) element(f23.x, z23.x, n23.x, omc[2], w, u);
-      if (e == 3) element(f23.y, z23.y, n23.y, omc[3], w, u);
+      if (e == 0) element(f01.x, z01.x, n01.x, omc[0], nl_cur & 0xFF, w, u);
+      if (e == 1) element(f01.y, z01.y, n01.y, omc[1], (nl_cur >> 8) & 0xFF, w, u);
+      if (e == 2) element(f23.x, z23.x, n23.x, omc[2], (nl_cur >> 16) & 0xFF, w, u);
+      if (e == 3) element(f23.y, z23.y, n23.y, omc[3], nl_cur >> 24, w, u);
       __builtin_amdgcn_sched_barrier(0);
       if (e == 1 && more) load01(c + 1);
       if (e == 3 && more) load23(c + 1);
@@ -685,6 +749,8 @@ struct TrainCoreArgs {
   const double *recP, *recE;
   const double *flux, *log_lya_1pz, *noise;
   const double *x;     // the parameter vector
+  const uint8_t *nl;   // [nq][ld] active lines per pixel (lines.nfl > 1 only)
+  TrainLines lines;
   double *wB, *uB;     // [PG][TQ][jj = quasar % 4][s = pixel % 16]: A operand of the dM contraction
   double *partcol, *partsc;
 };
@@ -697,6 +763,7 @@ constexpr size_t kTrCoreLds = 2 * TrC<20>::Ks * 64 * sizeof(double);  // k <= 20
 // (`ob`: this lane's offset in the pixel group's rows; zeros for missing and padded elements).
 struct TrainCoreRaw {
   double ye[4], lz[4], nv[4];
+  uint32_t nl[4];
 };
 // the tile's data, requested BEFORE the tile's MFMAs so that they arrive behind them (rows are
 // padded to 16 PG pixels with missing ones: no bound on p)
@@ -710,18 +777,21 @@ __device__ __forceinline__ void train_core_load(const TrainCoreArgs &a, int64_t 
     r.ye[rr] = a.flux[o];
     r.lz[rr] = a.log_lya_1pz[o];
     r.nv[rr] = a.noise[o];
+    r.nl[rr] = a.lines.nfl > 1 ? a.nl[o] : 1u;
   }
 }
 __device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t g, const TrainCoreRaw &raw, int jj, bool active, int64_t ob,
-                                                double om, double c_0, double tau_0, double beta, const d4 &X4,
-                                                const d4 &Y4, double &col, double &gc, double &gt, double &gb) {
+                                                double om, double c_0, double tau_0, double beta, const double *T_s,
+                                                const d4 &X4, const d4 &Y4, double &col, double &gc, double &gt,
+                                                double &gb) {
   const double *ye = raw.ye, *lz = raw.lz, *nv = raw.nv;
+  const bool lyseries = a.lines.nfl > 1;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const double y = ye[rr];
     double w = 0.0, u = 0.0;
     if (!isnan(y) && active && g * 16 + jj + 4 * rr < a.d.nq) {
-      const double od = tau_0 * fast_rcp(exp_nonpos(-beta * lz[rr]));  // :22 (as k_train_prepare)
+      const double od = (lyseries ? T_s[raw.nl[rr]] : tau_0) * fast_rcp(exp_nonpos(-beta * lz[rr]));  // :22 (as k_train_build)
       const double ab = exp_nonpos(-od);                        // :23
       const double sf = 1 - ab + c_0;                           // :26
       const double an = om * (sf * sf);                         // :27
@@ -783,6 +853,8 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   const int64_t p = pt * 16 + s;
   const TrainScal sc = train_scal(a.x, D.G, D.k);
   const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
+  __shared__ double T_s[kTrMaxLines + 1];
+  if (a.lines.nfl > 1 && threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);  // (published by the first group's barrier)
   double bP[K::Ks];
 #pragma unroll
   for (int ks = 0; ks < K::Ks; ++ks) bP[ks] = active ? a.recP[(pt * K::Ks + ks) * 64 + lane] : 0.0;
@@ -826,7 +898,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
       yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], yv, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     const d4 xs = {x0[0] + x1[0], x0[1] + x1[1], x0[2] + x1[2], x0[3] + x1[3]};
-    train_core_tile(a, g, raw, jj, active, ob, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
+    train_core_tile(a, g, raw, jj, active, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
   }
   if (!active) return;
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
@@ -835,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
 // 20 < k <= 40: 216 column steps -- too many B operands for the registers and 110 KB of A operands
 // per quasar group -- so both operands of every MFMA come straight from global memory (512
 // contiguous bytes per wave and step, L2 / MALL resident: recE is 34 MB for 5000 quasars), four
-// accumulator chains.  One wave per (pixel group, split); no LDS, no barriers.
+// accumulator chains.  One wave per (pixel group, split); no LDS operands, no barriers in the loop.
 __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
   using K = TrC<40>;
   const TrainDims &D = a.d;
@@ -843,12 +915,17 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
   const int64_t pblk = blockIdx.x / D.GS;
   const int gs = (int)(blockIdx.x % D.GS);
   const int64_t pt = pblk * 4 + wave;
-  if (pt >= D.PG) return;
   const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;
   const int jj = lane >> 4, s = lane & 15;
   const int64_t p = pt * 16 + s;
   const TrainScal sc = train_scal(a.x, D.G, D.k);
   const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
+  __shared__ double T_s[kTrMaxLines + 1];
+  if (a.lines.nfl > 1) {  // block-uniform
+    if (threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);
+    __syncthreads();
+  }
+  if (pt >= D.PG) return;
   const double om = p < D.G ? train_omega2(a.x, D.G, D.k, p) : 0.0;
   const int64_t ob = pt * D.TQ * 64 + lane;
   const double *bp = a.recP + pt * K::Ks * 64 + lane;
@@ -872,7 +949,7 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
                    (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
-    train_core_tile(a, g, raw, jj, true, ob, om, c_0, tau_0, beta, xs, yv, col, gc, gt, gb);
+    train_core_tile(a, g, raw, jj, true, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
   }
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
 }

@@ -1,7 +1,8 @@
 """Training objective of the GP quasar model on the GPU.
 
 Mirrors ``objective.m`` / ``spectrum_loss.m``: ``objective(x, centered_rest_fluxes, lya_1pzs,
-rest_noise_variances)`` returns ``(f, g)`` for ``x = [vec M; log omega; log c0; log tau0; log beta]``.
+rest_noise_variances)`` returns ``(f, g)`` for ``x = [vec M; log omega; log c0; log tau0; log beta]``;
+``objective_lyseries`` is the mean-flux model's form (multi_dlas/objective_lyseries.m).
 :class:`TrainingSet` keeps the three [num_quasars x num_pixels] matrices resident in HBM so an
 L-BFGS driver (the reference uses the third-party minFunc, learn_qso_model.m:100-101) pays only for
 ``x`` and ``g`` per iteration; :func:`fit` is that driver, on :func:`minimize_lbfgs` (minFunc's
@@ -45,6 +46,21 @@ class TrainingSet:
                                                      C.byref(f), g.ctypes.data_as(_dp)))
         return f.value, g
 
+    def set_lyseries(self, num_forest_lines: int, all_transition_wavelengths=None, all_oscillator_strengths=None):
+        """Switch to the mean-flux model's objective (multi_dlas/objective_lyseries.m over
+        spectrum_loss_lyseries.m): the optical depth sums the first ``num_forest_lines`` Lyman lines,
+        each counted where its redshift does not exceed the quasar's.  The two tables default to
+        set_parameters_multi.m:76-143; ``num_forest_lines <= 1`` switches back to objective.m."""
+        wl = fs = None
+        if all_transition_wavelengths is not None or all_oscillator_strengths is not None:
+            wl = np.ascontiguousarray(all_transition_wavelengths, dtype=np.float64).reshape(-1)
+            fs = np.ascontiguousarray(all_oscillator_strengths, dtype=np.float64).reshape(-1)
+            if wl.size < num_forest_lines or fs.size < num_forest_lines:
+                raise _lib.GpdlaError(-1, f"{num_forest_lines} lines asked for, tables hold {wl.size} / {fs.size}")
+        _lib.check(self.lib.gpdla_training_set_lyseries(self._h, int(num_forest_lines),
+                                                        None if wl is None else wl.ctypes.data_as(_dp),
+                                                        None if fs is None else fs.ctypes.data_as(_dp)))
+
     def close(self):
         if self._h:
             self.lib.gpdla_training_destroy(self._h)
@@ -61,6 +77,19 @@ def objective(x, centered_rest_fluxes, lya_1pzs, rest_noise_variances, device: i
     """``[f, g] = objective(x, centered_rest_fluxes, lya_1pzs, rest_noise_variances)`` (objective.m:12)."""
     t = TrainingSet(centered_rest_fluxes, lya_1pzs, rest_noise_variances, device)
     try:
+        return t.objective(x)
+    finally:
+        t.close()
+
+
+def objective_lyseries(x, centered_rest_fluxes, lya_1pzs, rest_noise_variances, num_forest_lines,
+                       all_transition_wavelengths=None, all_oscillator_strengths=None, device: int = 0):
+    """``[f, g] = objective_lyseries(x, centered_rest_fluxes, lya_1pzs, rest_noise_variances,
+    num_forest_lines, all_transition_wavelengths, all_oscillator_strengths)``
+    (multi_dlas/objective_lyseries.m:12-14)."""
+    t = TrainingSet(centered_rest_fluxes, lya_1pzs, rest_noise_variances, device)
+    try:
+        t.set_lyseries(num_forest_lines, all_transition_wavelengths, all_oscillator_strengths)
         return t.objective(x)
     finally:
         t.close()
@@ -279,12 +308,20 @@ def prior_value(x):
 
 
 def fit(initial_x, centered_rest_fluxes, lya_1pzs, rest_noise_variances, max_iter: int = 2000,
-        max_fun_evals: int = 4000, device: int = 0, prior_in_value: bool = False):
+        max_fun_evals: int = 4000, device: int = 0, prior_in_value: bool = False,
+        num_forest_lines: int = 0, all_transition_wavelengths=None, all_oscillator_strengths=None):
     """``[x, log_likelihood, ~, minFunc_output] = minFunc(objective_function, initial_x,
     minFunc_options)`` of learn_qso_model.m:100-101 with the objective evaluated on the GPU
     (set_parameters.m:43-45: MaxIter 2000, MaxFunEvals 4000).  Returns (x, f, FitResult); f is the
-    reference's objective value (without the prior term) in either mode."""
+    reference's objective value (without the prior term) in either mode.  ``num_forest_lines > 1``:
+    the mean-flux model's objective (multi_dlas/learn_qso_model_meanflux.m:140-147)."""
     t = TrainingSet(centered_rest_fluxes, lya_1pzs, rest_noise_variances, device)
+    if num_forest_lines > 1:
+        try:
+            t.set_lyseries(num_forest_lines, all_transition_wavelengths, all_oscillator_strengths)
+        except BaseException:
+            t.close()
+            raise
 
     def safe(x):
         try:

@@ -38,7 +38,7 @@ typedef enum {
 } gpdla_status;
 
 #define GPDLA_MAX_K 40
-#define GPDLA_ABI_VERSION 3
+#define GPDLA_ABI_VERSION 4
 
 int gpdla_abi_version(void);
 /* Human-readable text of the most recent error on this thread (never NULL). */
@@ -304,6 +304,16 @@ int gpdla_training_create(int device_id, int64_t num_quasars, int64_t num_pixels
                           const double *centered_rest_fluxes, const double *lya_1pzs,
                           const double *rest_noise_variances, gpdla_training **out);
 int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *f, double *g);
+/* Switches the training set to the mean-flux model's objective, multi_dlas/objective_lyseries.m:12-78
+ * over multi_dlas/spectrum_loss_lyseries.m:14-93 (what multi_dlas/learn_qso_model_meanflux.m:140-142
+ * minimises): the optical depth of a pixel sums the first num_forest_lines Lyman lines, each counted
+ * only where its redshift does not exceed the quasar's (zqso + 1 = the quasar's last lya_1pz,
+ * objective_lyseries.m:46); everything else is objective.m.  all_transition_wavelengths (any unit,
+ * decreasing) / all_oscillator_strengths: num_forest_lines entries each, or both NULL for the table
+ * of set_parameters_multi.m:76-143 (include/gpdla_lyman_series.h).  num_forest_lines <= 1 switches
+ * back to objective.m.  Takes effect from the next gpdla_training_objective call. */
+int gpdla_training_set_lyseries(gpdla_training *t, int num_forest_lines, const double *all_transition_wavelengths,
+                                const double *all_oscillator_strengths);
 void gpdla_training_destroy(gpdla_training *t);
 
 /* ---------------------------------------------------------------------------------------------

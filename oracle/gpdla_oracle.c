@@ -657,11 +657,16 @@ int gpdla_oracle_process_spectrum_multi(
  * Training objective: spectrum_loss.m:14-76 and objective.m:12-75,
  * as written.  M is n x k column-major; dM likewise.
  * ------------------------------------------------------------------------------------------ */
-int gpdla_oracle_spectrum_loss(const double *y, const double *lya_1pz, const double *noise_variance,
-                               const double *M, const double *omega2, int64_t n, int k, double c_0,
-                               double tau_0, double beta, double *nlog_p, double *dM,
-                               double *dlog_omega, double *dlog_c_0, double *dlog_tau_0,
-                               double *dlog_beta) {
+/* The two spectrum losses differ in the optical depth only: spectrum_loss.m:22 (Lyman alpha) or
+ * multi_dlas/spectrum_loss_lyseries.m:22-39 (Lyman alpha plus num_forest_lines - 1 higher lines, each
+ * switched off where its redshift would exceed the quasar's).  Lines :23-75 of the former are lines
+ * :40-92 of the latter, word for word (line cites below: spectrum_loss.m). */
+static int spectrum_loss_body(const double *y, const double *lya_1pz, const double *noise_variance,
+                              const double *M, const double *omega2, int64_t n, int k, double c_0,
+                              double tau_0, double beta, int num_forest_lines,
+                              const double *all_transition_wavelengths, const double *all_oscillator_strengths,
+                              double zqso_1pz, double *nlog_p, double *dM, double *dlog_omega,
+                              double *dlog_c_0, double *dlog_tau_0, double *dlog_beta) {
   const double log_2pi = 1.83787706640934534; /* :17 */
   size_t nn = (size_t)n;
   double *lya_optical_depth = (double *)malloc(sizeof(double) * nn);
@@ -684,6 +689,14 @@ int gpdla_oracle_spectrum_loss(const double *y, const double *lya_1pz, const dou
   int rc = 0;
   for (int64_t i = 0; i < n; i++) {
     lya_optical_depth[i] = tau_0 * pow(lya_1pz[i], beta);                 /* :22 */
+    for (int l = 1; l < num_forest_lines; l++) {                          /* spectrum_loss_lyseries.m:27-38 */
+      double lyman_1pz = all_transition_wavelengths[0] * lya_1pz[i] / all_transition_wavelengths[l];
+      const double indicator = lyman_1pz <= zqso_1pz ? 1.0 : 0.0;
+      lyman_1pz = lyman_1pz * indicator;
+      const double tau = tau_0 * all_transition_wavelengths[l] * all_oscillator_strengths[l] /
+                         (all_transition_wavelengths[0] * all_oscillator_strengths[0]);
+      lya_optical_depth[i] = lya_optical_depth[i] + tau * pow(lyman_1pz, beta);
+    }
     lya_absorption[i] = exp(-lya_optical_depth[i]);                       /* :23 */
     scaling_factor[i] = 1 - lya_absorption[i] + c_0;                      /* :26 */
     absorption_noise[i] = omega2[i] * (scaling_factor[i] * scaling_factor[i]); /* :27 */
@@ -785,12 +798,35 @@ done:
   return rc;
 }
 
+int gpdla_oracle_spectrum_loss(const double *y, const double *lya_1pz, const double *noise_variance,
+                               const double *M, const double *omega2, int64_t n, int k, double c_0,
+                               double tau_0, double beta, double *nlog_p, double *dM,
+                               double *dlog_omega, double *dlog_c_0, double *dlog_tau_0,
+                               double *dlog_beta) {
+  return spectrum_loss_body(y, lya_1pz, noise_variance, M, omega2, n, k, c_0, tau_0, beta, 1, NULL, NULL, 0.0,
+                            nlog_p, dM, dlog_omega, dlog_c_0, dlog_tau_0, dlog_beta);
+}
+
+/* multi_dlas/spectrum_loss_lyseries.m:14-93 */
+int gpdla_oracle_spectrum_loss_lyseries(const double *y, const double *lya_1pz, const double *noise_variance,
+                                        const double *M, const double *omega2, int64_t n, int k, double c_0,
+                                        double tau_0, double beta, int num_forest_lines,
+                                        const double *all_transition_wavelengths,
+                                        const double *all_oscillator_strengths, double zqso_1pz,
+                                        double *nlog_p, double *dM, double *dlog_omega, double *dlog_c_0,
+                                        double *dlog_tau_0, double *dlog_beta) {
+  return spectrum_loss_body(y, lya_1pz, noise_variance, M, omega2, n, k, c_0, tau_0, beta, num_forest_lines,
+                            all_transition_wavelengths, all_oscillator_strengths, zqso_1pz, nlog_p, dM,
+                            dlog_omega, dlog_c_0, dlog_tau_0, dlog_beta);
+}
+
 /* objective.m:12-75.  The three data matrices are [num_quasars x num_pixels] column-major with NaN
  * marking missing pixels (:42); x = [vec M; log omega; log c0; log tau0; log beta] (:5). */
-int gpdla_oracle_objective(const double *x, int64_t num_quasars, int64_t num_pixels, int k,
-                           const double *centered_rest_fluxes, const double *lya_1pzs,
-                           const double *rest_noise_variances, int num_threads, double *f,
-                           double *g) {
+static int objective_body(const double *x, int64_t num_quasars, int64_t num_pixels, int k,
+                          const double *centered_rest_fluxes, const double *lya_1pzs,
+                          const double *rest_noise_variances, int num_forest_lines,
+                          const double *all_transition_wavelengths, const double *all_oscillator_strengths,
+                          int num_threads, double *f, double *g) {
   const size_t G = (size_t)num_pixels;
   const double *M = x, *log_omega = x + G * k;
   const double log_c_0 = x[G * (k + 1)], log_tau_0 = x[G * (k + 1) + 1], log_beta = x[G * (k + 1) + 2];
@@ -831,8 +867,11 @@ int gpdla_oracle_objective(const double *x, int64_t num_quasars, int64_t num_pix
       for (int a = 0; a < k; a++)
         for (int64_t j = 0; j < n; j++) Mi[j + a * n] = M[idx[j] + a * G];
       double tf, tc, tt, tb;
-      if (gpdla_oracle_spectrum_loss(y, l1, nv, Mi, om, n, k, c_0, tau_0, beta, &tf, dM, dlo, &tc,
-                                     &tt, &tb)) {
+      /* objective_lyseries.m:46: zqso + 1 is the quasar's last lya_1pz */
+      const double zqso_1pz = lya_1pzs[i + (G - 1) * num_quasars];
+      if (spectrum_loss_body(y, l1, nv, Mi, om, n, k, c_0, tau_0, beta, num_forest_lines,
+                             all_transition_wavelengths, all_oscillator_strengths, zqso_1pz, &tf, dM, dlo,
+                             &tc, &tt, &tb)) {
 #pragma omp atomic write
         fail = 1;
         continue;
@@ -865,4 +904,24 @@ int gpdla_oracle_objective(const double *x, int64_t num_quasars, int64_t num_pix
   *f = fsum;
   free(omega2);
   return fail ? -1 : 0;
+}
+
+int gpdla_oracle_objective(const double *x, int64_t num_quasars, int64_t num_pixels, int k,
+                           const double *centered_rest_fluxes, const double *lya_1pzs,
+                           const double *rest_noise_variances, int num_threads, double *f,
+                           double *g) {
+  return objective_body(x, num_quasars, num_pixels, k, centered_rest_fluxes, lya_1pzs, rest_noise_variances, 1,
+                        NULL, NULL, num_threads, f, g);
+}
+
+/* multi_dlas/objective_lyseries.m:12-78 (objective.m with spectrum_loss_lyseries in place of spectrum_loss) */
+int gpdla_oracle_objective_lyseries(const double *x, int64_t num_quasars, int64_t num_pixels, int k,
+                                    const double *centered_rest_fluxes, const double *lya_1pzs,
+                                    const double *rest_noise_variances, int num_forest_lines,
+                                    const double *all_transition_wavelengths,
+                                    const double *all_oscillator_strengths, int num_threads, double *f,
+                                    double *g) {
+  if (num_forest_lines < 1 || !all_transition_wavelengths || !all_oscillator_strengths) return -2;
+  return objective_body(x, num_quasars, num_pixels, k, centered_rest_fluxes, lya_1pzs, rest_noise_variances,
+                        num_forest_lines, all_transition_wavelengths, all_oscillator_strengths, num_threads, f, g);
 }

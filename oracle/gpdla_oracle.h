@@ -11,6 +11,7 @@
  *   process_qsos.m:96-213           (per-spectrum driver: selection, interpolation, sweep, evidence)
  *   multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-477 (multi-DLA / LLS / mean-flux driver)
  *   spectrum_loss.m:14-76, objective.m:12-75 (training objective and gradient, "next" row N3)
+ *   multi_dlas/spectrum_loss_lyseries.m:14-93, objective_lyseries.m:12-78 (the same for the mean-flux model)
  *
  * Third-party arithmetic: voigt.c:288 calls libcerf's  double voigt(double x, double sigma,
  * double gamma)  (libcerf is NOT in /root/reference and its version is not pinned anywhere,
@@ -153,6 +154,23 @@ int gpdla_oracle_objective(const double *x, int64_t num_quasars, int64_t num_pix
                            const double *centered_rest_fluxes, const double *lya_1pzs,
                            const double *rest_noise_variances, int num_threads, double *f,
                            double *g);
+
+/* multi_dlas/spectrum_loss_lyseries.m:14-93 and multi_dlas/objective_lyseries.m:12-78: the training
+ * objective of the mean-flux (multi-DLA) model -- the optical depth sums num_forest_lines Lyman
+ * lines, each switched off beyond the quasar's own redshift (zqso_1pz = the quasar's last lya_1pz). */
+int gpdla_oracle_spectrum_loss_lyseries(const double *y, const double *lya_1pz, const double *noise_variance,
+                                        const double *M, const double *omega2, int64_t n, int k, double c_0,
+                                        double tau_0, double beta, int num_forest_lines,
+                                        const double *all_transition_wavelengths,
+                                        const double *all_oscillator_strengths, double zqso_1pz,
+                                        double *nlog_p, double *dM, double *dlog_omega, double *dlog_c_0,
+                                        double *dlog_tau_0, double *dlog_beta);
+int gpdla_oracle_objective_lyseries(const double *x, int64_t num_quasars, int64_t num_pixels, int k,
+                                    const double *centered_rest_fluxes, const double *lya_1pzs,
+                                    const double *rest_noise_variances, int num_forest_lines,
+                                    const double *all_transition_wavelengths,
+                                    const double *all_oscillator_strengths, int num_threads, double *f,
+                                    double *g);
 
 #ifdef __cplusplus
 }

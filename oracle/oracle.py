@@ -291,6 +291,34 @@ def process_spectrum_multi(model, offset_samples, nhi_samples, log_nhi_samples, 
                 MAP_log_nhis=np.array(mapn), MAP_inds=np.array(mapi))
 
 
+def objective_lyseries(x, centered_rest_fluxes, lya_1pzs, rest_noise_variances, num_forest_lines,
+                       all_transition_wavelengths, all_oscillator_strengths, num_threads=0):
+    """multi_dlas/objective_lyseries.m:12-78 (same arguments): (f, g) of the mean-flux model's
+    training objective."""
+    lib = load()
+    F = np.asfortranarray(centered_rest_fluxes, dtype=np.float64)
+    Lz = np.asfortranarray(lya_1pzs, dtype=np.float64)
+    Nv = np.asfortranarray(rest_noise_variances, dtype=np.float64)
+    nq, G = F.shape
+    x, xp = _d(x)
+    k = (x.size - 3) // G - 1
+    assert x.size == G * (k + 1) + 3
+    wl, wlp = _d(all_transition_wavelengths)
+    fs, fsp = _d(all_oscillator_strengths)
+    assert wl.size >= num_forest_lines and fs.size >= num_forest_lines
+    f = C.c_double()
+    g = np.zeros_like(x)
+    lib.gpdla_oracle_objective_lyseries.restype = C.c_int
+    lib.gpdla_oracle_objective_lyseries.argtypes = [_dp, C.c_int64, C.c_int64, C.c_int, _dp, _dp, _dp, C.c_int,
+                                                    _dp, _dp, C.c_int, _dp, _dp]
+    rc = lib.gpdla_oracle_objective_lyseries(xp, nq, G, k, F.ctypes.data_as(_dp), Lz.ctypes.data_as(_dp),
+                                             Nv.ctypes.data_as(_dp), int(num_forest_lines), wlp, fsp,
+                                             int(num_threads), C.byref(f), g.ctypes.data_as(_dp))
+    if rc:
+        raise ValueError("oracle objective_lyseries: B not positive definite" if rc == -1 else "bad arguments")
+    return f.value, g
+
+
 def objective(x, centered_rest_fluxes, lya_1pzs, rest_noise_variances, num_threads=0):
     """objective.m:12-75: (f, g) for x = [vec M; log omega; log c0; log tau0; log beta]; the data
     matrices are (num_quasars, num_pixels) with NaN for missing pixels."""

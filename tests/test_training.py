@@ -201,3 +201,86 @@ def test_gpu_objective_not_positive_definite_is_reported():
     with pytest.raises(_lib.GpdlaError) as e:
         training.objective(x, F, L1, NV)
     assert e.value.code == -4
+
+
+# ---------------------------------------------------------------------------------------------
+# the mean-flux model's objective: multi_dlas/objective_lyseries.m over spectrum_loss_lyseries.m
+# ---------------------------------------------------------------------------------------------
+
+def lyseries_problem(nq=24, G=72, k=5, seed=3):
+    """A training set in which the Lyman-series cut-offs bite: rest wavelengths from the Lyman limit
+    to Lyman alpha, so the higher lines of a pixel fall beyond the quasar for part of the grid."""
+    rng = np.random.default_rng(seed)
+    x, F, _, NV = training_problem(nq=nq, G=G, k=k, seed=seed)
+    rest = np.linspace(911.75, 1215.6701, G)
+    L1 = (1 + rng.uniform(2.1, 4.5, nq))[:, None] * rest[None, :] / 1215.6701  # lya_1pzs; last column = 1 + z_qso
+    return x, F, L1, NV
+
+
+def series_tables():
+    from gp_dla_detection_amd import _lyman_data as ld  # (wavelength [cm], oscillator strength, ...) per line
+    wl = np.array([line[0] * 1e8 for line in ld.LINES])   # set_parameters_multi.m:77-108: the same numbers, in Angstrom
+    fs = np.array([line[1] for line in ld.LINES])
+    return wl, fs
+
+
+def test_oracle_lyseries_objective(oracle):
+    """One line is the plain objective, bit for bit; with six lines the value moves and the gradient
+    agrees with finite differences for M, log omega, log c0 and log tau0 (the log beta entry is the
+    reference's as-written expression, spectrum_loss_lyseries.m:90, which uses log(lya_1pz) for
+    every line -- not a derivative of the value when more than one line is on)."""
+    x, F, L1, NV = lyseries_problem()
+    wl, fs = series_tables()
+    f1, g1 = oracle.objective(x, F, L1, NV, num_threads=1)  # (one thread: the oracle's sums over quasars are then ordered)
+    f1b, g1b = oracle.objective_lyseries(x, F, L1, NV, 1, wl, fs, num_threads=1)
+    assert f1 == f1b and np.array_equal(g1, g1b)
+    f6, g6 = oracle.objective_lyseries(x, F, L1, NV, 6, wl, fs)
+    assert abs(f6 - f1) > 1e-3
+    t0 = np.exp(x[-2])
+    prior_t = t0 * (t0 - 0.0023) / 0.0007 ** 2
+    rng = np.random.default_rng(1)
+    for i in list(rng.choice(x.size - 3, 8, replace=False)) + [x.size - 3, x.size - 2]:
+        e = np.zeros(x.size)
+        e[i] = 1e-6
+        fd = (oracle.objective_lyseries(x + e, F, L1, NV, 6, wl, fs)[0]
+              - oracle.objective_lyseries(x - e, F, L1, NV, 6, wl, fs)[0]) / 2e-6
+        assert abs(g6[i] - (prior_t if i == x.size - 2 else 0.0) - fd) < 1e-6 * max(1.0, abs(fd)), i
+
+
+@pytest.mark.gpu
+def test_gpu_lyseries_objective_matches_the_oracle(oracle):
+    """gpdla_training_set_lyseries: 1 line = the plain objective bit for bit; 6 and 31 lines (the
+    library's own table and a caller's) agree with the oracle to 1e-9 relative on ragged shapes in
+    both rank classes; switching back restores the plain objective; bad tables are refused."""
+    from gp_dla_detection_amd import _lib, training
+    wl, fs = series_tables()
+    for (nq, G, k) in ((24, 72, 5), (37, 203, 20), (9, 130, 33)):
+        x, F, L1, NV = lyseries_problem(nq=nq, G=G, k=k, seed=40 + k)
+        t = training.TrainingSet(F, L1, NV)
+        try:
+            f0, g0 = t.objective(x)
+            t.set_lyseries(1)
+            f1, g1 = t.objective(x)
+            assert f0 == f1 and np.array_equal(g0, g1), (nq, G, k)
+            for nfl, tables in ((6, (None, None)), (31, (wl, fs)), (3, (wl[:3] * 7.0, fs[:3]))):  # (any unit)
+                t.set_lyseries(nfl, *tables)
+                f, g = t.objective(x)
+                f2, g2 = t.objective(x)
+                assert f == f2 and np.array_equal(g, g2)  # deterministic
+                f_ref, g_ref = oracle.objective_lyseries(x, F, L1, NV, nfl, wl, fs)
+                assert abs(f - f_ref) < 1e-9 * abs(f_ref), (nq, G, k, nfl, f, f_ref)
+                assert np.abs(g - g_ref).max() < 1e-9 * np.abs(g_ref).max(), (nq, G, k, nfl)
+                assert abs(f - f0) > 1e-6 * abs(f0)  # the extra lines do something on this grid
+            t.set_lyseries(0)
+            f3, g3 = t.objective(x)
+            assert f3 == f0 and np.array_equal(g3, g0)
+            with pytest.raises(_lib.GpdlaError):
+                t.set_lyseries(3, wl[[0, 2, 1]], fs[:3])  # not decreasing
+            with pytest.raises(_lib.GpdlaError):
+                t.set_lyseries(40)
+        finally:
+            t.close()
+    x, F, L1, NV = lyseries_problem()
+    f, g = training.objective_lyseries(x, F, L1, NV, 6, wl, fs)
+    f_ref, g_ref = oracle.objective_lyseries(x, F, L1, NV, 6, wl, fs)
+    assert abs(f - f_ref) < 1e-9 * abs(f_ref) and np.abs(g - g_ref).max() < 1e-9 * np.abs(g_ref).max()

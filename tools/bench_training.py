@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--quasars", type=int, default=5000)
 ap.add_argument("--pixels", type=int, default=1217)
 ap.add_argument("--k", type=int, default=20)
+ap.add_argument("--forest-lines", type=int, default=0, help="> 1: the mean-flux model's objective (objective_lyseries.m)")
 args = ap.parse_args()
 rng = np.random.default_rng(0)
 nq, G, k = args.quasars, args.pixels, args.k
@@ -27,6 +28,8 @@ NV = 10 ** rng.uniform(-3, -1, (nq, G))
 F = rng.standard_normal((nq, k)) @ M.T + np.sqrt(NV) * rng.standard_normal((nq, G))
 F[rng.uniform(size=F.shape) < 0.1] = np.nan
 t = training.TrainingSet(F, L1, NV)
+if args.forest_lines > 1:
+    t.set_lyseries(args.forest_lines)
 t.objective(x)
 t0 = time.perf_counter()
 reps = 5
@@ -43,4 +46,4 @@ flops = nq * (0.9 * G) * (3 * k * k + 10 * k) * 1.0
 print(json.dumps({"metric": "training objective evaluations (value + gradient)", "quasars": nq, "pixels": G, "k": k,
                   "gpu_seconds_per_eval": gpu_s, "gpu_quasars_per_s": nq / gpu_s,
                   "cpu_oracle_quasars_per_s": sub / cpu_s, "cpu_threads": len(os.sched_getaffinity(0)),
-                  "gpu_gflops_algorithmic": flops / gpu_s / 1e9}))
+                  "gpu_gflops_algorithmic": flops / gpu_s / 1e9, "forest_lines": args.forest_lines}))
