@@ -1669,7 +1669,10 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   ba.group_stride = strideM;
   ba.out = t->d_partB;
   ba.part1 = t->d_part1;
-  hipLaunchKernelGGL(k_train_build, dim3((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H * K::Groups)), dim3(kTrCWaves * 64), kTrBuildLds, st, ba);
+  const bool ly = t->lines.nfl > 1;
+  const dim3 build_grid((unsigned)(((d.NQ16 + kTrCWaves - 1) / kTrCWaves) * d.H * K::Groups));
+  if (ly) hipLaunchKernelGGL(k_train_build<true>, build_grid, dim3(kTrCWaves * 64), kTrBuildLds, st, ba);
+  else hipLaunchKernelGGL(k_train_build<false>, build_grid, dim3(kTrCWaves * 64), kTrBuildLds, st, ba);
   TrainFactorArgs fa;
   fa.d = d;
   fa.partB = t->d_partB;
@@ -1694,10 +1697,14 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   co.uB = t->d_uB;
   co.partcol = t->d_partcol;
   co.partsc = t->d_partsc;
-  if (KMAX <= 20)
-    hipLaunchKernelGGL(k_train_core, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), kTrCoreLds, st, co);
-  else
-    hipLaunchKernelGGL(k_train_core_wide, dim3((unsigned)(((d.PG + 3) / 4) * d.GS)), dim3(256), 0, st, co);
+  const dim3 core_grid((unsigned)(((d.PG + 3) / 4) * d.GS));
+  if (KMAX <= 20) {
+    if (ly) hipLaunchKernelGGL(k_train_core<true>, core_grid, dim3(256), kTrCoreLds, st, co);
+    else hipLaunchKernelGGL(k_train_core<false>, core_grid, dim3(256), kTrCoreLds, st, co);
+  } else {
+    if (ly) hipLaunchKernelGGL(k_train_core_wide<true>, core_grid, dim3(256), 0, st, co);
+    else hipLaunchKernelGGL(k_train_core_wide<false>, core_grid, dim3(256), 0, st, co);
+  }
   TrainContractArgs ca;  // dM: rows = pixels, steps over quasars
   ca.Aw = t->d_wB;
   ca.Au = t->d_uB;
@@ -1753,9 +1760,13 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
     HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_contract),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrContractLds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_build),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_build<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrBuildLds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_core),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_build<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrBuildLds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_core<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrCoreLds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_train_core<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrCoreLds));
     return GPDLA_OK;
     };

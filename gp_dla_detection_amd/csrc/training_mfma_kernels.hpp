@@ -365,7 +365,8 @@ struct TrainBuildArgs {
   double *part1;
 };
 
-template <int NW>
+// LY: the Lyman-series objective (lines.nfl > 1), a compile-time switch so that the plain objective pays nothing for it
+template <int NW, bool LY>
 __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double *smem, int tg) {
   const TrainDims &D = a.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -395,7 +396,7 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
   // omega2 of the split's pixels: once per block, behind the two record buffers; then the line table
   double *om_s = smem + 2 * kTrChunk * kTrGroupD;
   for (int e = threadIdx.x; e < 16 * nchunks; e += kTrCWaves * 64) om_s[e] = a.omega2[16 * c0 + e];
-  const bool lyseries = a.lines.nfl > 1;  // block-uniform
+  constexpr bool lyseries = LY;
   double *T_s = om_s + 16 * kTrBuildMaxChunks;
   if (lyseries && threadIdx.x == 0) train_line_table(a.lines, sc.tau_0, sc.beta, T_s);
   const uint32_t *pl = reinterpret_cast<const uint32_t *>(a.nl + (lyseries ? row : 0));
@@ -494,13 +495,14 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
   }
 }
 
+template <bool LY>
 __global__ __launch_bounds__(kTrCWaves * 64, 2) void k_train_build(TrainBuildArgs a) {
   extern __shared__ double smem[];
   const int tg = (int)(blockIdx.x % a.groups);
   const int nw = max(0, min(16, a.w_tiles - 16 * tg));  // block-uniform: 14 (k <= 20); 16, 16, 16, 4 (k <= 40)
-  if (nw == 16) train_build_body<16>(a, smem, tg);
-  else if (nw == 14) train_build_body<14>(a, smem, tg);
-  else train_build_body<4>(a, smem, tg);
+  if (nw == 16) train_build_body<16, LY>(a, smem, tg);
+  else if (nw == 14) train_build_body<14, LY>(a, smem, tg);
+  else train_build_body<4, LY>(a, smem, tg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -767,6 +769,7 @@ struct TrainCoreRaw {
 };
 // the tile's data, requested BEFORE the tile's MFMAs so that they arrive behind them (rows are
 // padded to 16 PG pixels with missing ones: no bound on p)
+template <bool LY>
 __device__ __forceinline__ void train_core_load(const TrainCoreArgs &a, int64_t g, int64_t p, int jj, bool active,
                                                 TrainCoreRaw &r) {
   const TrainDims &D = a.d;
@@ -777,15 +780,16 @@ __device__ __forceinline__ void train_core_load(const TrainCoreArgs &a, int64_t 
     r.ye[rr] = a.flux[o];
     r.lz[rr] = a.log_lya_1pz[o];
     r.nv[rr] = a.noise[o];
-    r.nl[rr] = a.lines.nfl > 1 ? a.nl[o] : 1u;
+    r.nl[rr] = LY ? a.nl[o] : 1u;
   }
 }
+template <bool LY>
 __device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t g, const TrainCoreRaw &raw, int jj, bool active, int64_t ob,
                                                 double om, double c_0, double tau_0, double beta, const double *T_s,
                                                 const d4 &X4, const d4 &Y4, double &col, double &gc, double &gt,
                                                 double &gb) {
   const double *ye = raw.ye, *lz = raw.lz, *nv = raw.nv;
-  const bool lyseries = a.lines.nfl > 1;
+  constexpr bool lyseries = LY;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const double y = ye[rr];
@@ -839,6 +843,7 @@ __device__ __forceinline__ void train_core_store(const TrainCoreArgs &a, int64_t
 // k <= 20.  A block is 4 waves = 4 pixel groups that walk the SAME quasar groups (split gs): the A
 // operands of a quasar group ([vech2(T_q) | z_q] of its 16 quasars, 29 KB) are staged once per
 // block, double-buffered by glds16; the B operands of the wave's pixel group stay in registers.
+template <bool LY>
 __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   extern __shared__ double smem[];
   using K = TrC<20>;
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   const TrainScal sc = train_scal(a.x, D.G, D.k);
   const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
   __shared__ double T_s[kTrMaxLines + 1];
-  if (a.lines.nfl > 1 && threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);  // (published by the first group's barrier)
+  if (LY && threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);  // (published by the first group's barrier)
   double bP[K::Ks];
 #pragma unroll
   for (int ks = 0; ks < K::Ks; ++ks) bP[ks] = active ? a.recP[(pt * K::Ks + ks) * 64 + lane] : 0.0;
@@ -883,7 +888,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
     if (g + 1 < g1) issue_group(g + 1);
     const double *re = smem + (size_t)((g - g0) & 1) * K::Ks * 64 + lane;
     TrainCoreRaw raw;
-    train_core_load(a, g, p, jj, active, raw);
+    train_core_load<LY>(a, g, p, jj, active, raw);
     __builtin_amdgcn_sched_barrier(0);  // (nothing that waits for these loads may move in front of the MFMAs)
     // two accumulator chains for X (registers: the kernel must stay within 256 per lane so that
     // two waves share a SIMD), one for Y
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
       yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], yv, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     const d4 xs = {x0[0] + x1[0], x0[1] + x1[1], x0[2] + x1[2], x0[3] + x1[3]};
-    train_core_tile(a, g, raw, jj, active, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
+    train_core_tile<LY>(a, g, raw, jj, active, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
   }
   if (!active) return;
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
@@ -908,6 +913,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
 // per quasar group -- so both operands of every MFMA come straight from global memory (512
 // contiguous bytes per wave and step, L2 / MALL resident: recE is 34 MB for 5000 quasars), four
 // accumulator chains.  One wave per (pixel group, split); no LDS operands, no barriers in the loop.
+template <bool LY>
 __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
   using K = TrC<40>;
   const TrainDims &D = a.d;
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
   const TrainScal sc = train_scal(a.x, D.G, D.k);
   const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
   __shared__ double T_s[kTrMaxLines + 1];
-  if (a.lines.nfl > 1) {  // block-uniform
+  if (LY) {
     if (threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);
     __syncthreads();
   }
@@ -933,7 +939,7 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
   for (int64_t g = g0; g < g1; ++g) {
     const double *re = a.recE + g * K::Ks * 64 + lane;
     TrainCoreRaw raw;
-    train_core_load(a, g, p, jj, true, raw);
+    train_core_load<LY>(a, g, p, jj, true, raw);
     __builtin_amdgcn_sched_barrier(0);
     d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, x2 = x0, x3 = x0, yv = x0;
     for (int ks = 0; ks + 3 < K::KsW; ks += 4) {
@@ -949,7 +955,7 @@ __global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
                    (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
-    train_core_tile(a, g, raw, jj, true, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
+    train_core_tile<LY>(a, g, raw, jj, true, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
   }
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
 }
