@@ -289,8 +289,14 @@ def build_h5cells(force: bool = False) -> str:
     """gcc -O2 -fopenmp csrc/h5cells.c -lz -> csrc/libgpdla_h5cells.so (host code: no GPU involved)."""
     import subprocess
     if force or not os.path.exists(_H5CELLS_LIB) or os.path.getmtime(_H5CELLS_LIB) < os.path.getmtime(_H5CELLS_SRC):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-Wall", _H5CELLS_SRC, "-lz",
-                               "-o", _H5CELLS_LIB])
+        tmp = f"{_H5CELLS_LIB}.{os.getpid()}.tmp"  # the ranks of a run may all get here at once: publish atomically
+        try:
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-Wall", _H5CELLS_SRC, "-lz", "-o", tmp],
+                                  stderr=subprocess.DEVNULL if not force else None)
+            os.replace(tmp, _H5CELLS_LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return _H5CELLS_LIB
 
 
@@ -301,7 +307,8 @@ def _load_h5cells():
     if _h5cells is None:
         import ctypes as C
         try:
-            lib = C.CDLL(build_h5cells())
+            # an existing library is used as it is (__graft_entry__.build() refreshes it); a missing one is built
+            lib = C.CDLL(_H5CELLS_LIB if os.path.exists(_H5CELLS_LIB) else build_h5cells())
             lib.gpdla_h5cells_sizes.restype = C.c_int
             lib.gpdla_h5cells_sizes.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p,
                                                 C.c_void_p, C.c_int]
