@@ -544,8 +544,8 @@ class ProcessedStreamWriter:
     batch is swept (:meth:`append`, called by the pipeline's download thread); :meth:`finish`
     writes the per-quasar variables and the metadata.  The file holds the same variables with the
     same shapes and classes as the one-shot writers'; the large ones are chunked (as MATLAB's own
-    ``-v7.3`` files are) instead of contiguous.  ``batch``: quasars per batch -- every batch but the
-    last must have exactly that many."""
+    ``-v7.3`` files are) instead of contiguous.  ``batch``: the chunks' extent along the quasar axis --
+    every batch but the last must hold a whole multiple of it."""
 
     _TARGET = 8 << 20  # bytes per chunk, about
 
@@ -582,22 +582,23 @@ class ProcessedStreamWriter:
     def append(self, at: int, tables: dict) -> None:
         """The rows ``at .. at + n`` of the run: ``tables[name]`` = this package's orientation,
         [n, S] or [n, model, S]."""
-        n = None
+        n, B = None, self.B
         for name, (st, _) in self.streams.items():
             t = np.asarray(tables[name])
             n = t.shape[0] if n is None else n
-            if at % self.B or t.shape[0] != n or (n != self.B and at + n != self.nq):
-                raise ValueError(f"batch [{at}, {at + n}) does not sit on the {self.B}-quasar chunk grid")
+            if at % B or t.shape[0] != n or (n % B and at + n != self.nq):
+                raise ValueError(f"batch [{at}, {at + n}) does not sit on the {B}-quasar chunk grid")
             cs = st.chunks[-2]
-            if t.ndim == 2:
-                tt = np.ascontiguousarray(t.T)  # [S, n]
-                for r0 in range(0, self.S, cs):
-                    st.write_chunk((r0, at), tt[r0:r0 + cs])
-            else:
-                for mdl in range(t.shape[1]):
-                    tt = np.ascontiguousarray(t[:, mdl, :].T)
+            for c0 in range(0, n, B):  # a batch may span several chunk columns
+                if t.ndim == 2:
+                    tt = np.ascontiguousarray(t[c0:c0 + B].T)  # [S, <= B]
                     for r0 in range(0, self.S, cs):
-                        st.write_chunk((mdl, r0, at), tt[None, r0:r0 + cs])
+                        st.write_chunk((r0, at + c0), tt[r0:r0 + cs])
+                else:
+                    for mdl in range(t.shape[1]):
+                        tt = np.ascontiguousarray(t[c0:c0 + B, mdl, :].T)
+                        for r0 in range(0, self.S, cs):
+                            st.write_chunk((mdl, r0, at + c0), tt[None, r0:r0 + cs])
         self.done += n or 0
 
     def finish(self, results: dict, test_ind=None, **run_metadata) -> None:

@@ -56,6 +56,29 @@ def select_test_ind(catalog: dict, test_ind=None) -> np.ndarray:
     return t.astype(np.int64)
 
 
+def ramped_blocks(n: int, batch: int, ramp: int = 8):
+    """Batches of a pipelined run: ``batch`` quasars each, but a small first one and a small last one
+    (``batch // ramp``) -- the first batch's read + upload and the last batch's download + write are
+    the two stretches of a run that nothing overlaps.  Every batch but the last starts and ends on
+    a multiple of the returned grid (the chunk width of :class:`io.ProcessedStreamWriter`).
+    Returns ``([(lo, hi), ...], grid)``."""
+    batch = max(1, int(batch))
+    small = batch // ramp
+    if small < 16 or n <= batch:  # nothing to ramp: plain fixed-size batches
+        return batch_blocks(n, batch), batch
+    batch = (batch // small) * small
+    blocks, lo = [(0, small)], small
+    while n - lo > batch + small:
+        blocks.append((lo, lo + batch))
+        lo += batch
+    mid = ((n - lo - small) // small) * small  # what is left: a batch on the grid, then the small last one
+    if mid > 0:
+        blocks.append((lo, lo + mid))
+        lo += mid
+    blocks.append((lo, n))
+    return blocks, small
+
+
 def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file: str, out_dir: str,
         test_set_name: str = "dr12q", test_ind=None, prior_catalog: dict | None = None,
         multi: bool = False, params: Parameters | None = None, Z_lls: float | None = None,
@@ -116,13 +139,13 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
             if max_quasars_per_batch is None:
                 max_quasars_per_batch = default_batch_size(nloc, int(counts[lo:hi].max()), k, S, pipeline_slots,
                                                            multi_models=(p.max_dlas + 1) if multi else 0)
-            blocks = batch_blocks(nloc, max_quasars_per_batch)
+            blocks, grid = ramped_blocks(nloc, max_quasars_per_batch)
             local = (Batch.empty_results_multi(nloc, p.max_dlas, S) if multi else Batch.empty_results(nloc, S))
             ctx = Context(device, p, stream=stream)
             # the chunk file is open from the start: the download thread transposes each batch's
             # per-sample tables into MATLAB's order and writes them while the next batch is swept
             chunk = io.chunk_filename(out_dir, test_set_name, lo, hi, multi)
-            writer = io.ProcessedStreamWriter(chunk, nloc, S, blocks[0][1] - blocks[0][0], p.max_dlas if multi else 0)
+            writer = io.ProcessedStreamWriter(chunk, nloc, S, grid, p.max_dlas if multi else 0)
 
             def inputs(i):  # runs on the upload thread: file reads overlap the sweep in flight
                 b0, b1 = blocks[i]

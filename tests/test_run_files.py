@@ -102,3 +102,19 @@ def test_batch_size_defaults():
     assert default_batch_size(10 ** 6, 1500, 20, 10000, 3) == 4096
     # memory-bound case: a small HBM budget
     assert default_batch_size(10 ** 6, 1500, 40, 10000, 3, budget_bytes=2 ** 30) < 800
+
+
+def test_ramped_blocks_cover_the_run_on_the_chunk_grid():
+    """run_dr12q.ramped_blocks: contiguous cover, a small first and last batch, and every batch but
+    the last on the chunk grid of the streamed writer."""
+    from gp_dla_detection_amd.run_dr12q import ramped_blocks
+    for n, b in ((20358, 4096), (4000, 4096), (5000, 4096), (9000, 4096), (100, 2), (33, 16), (1000, 128),
+                 (4097, 4096), (5120, 4096), (130, 128), (1, 64), (512, 512), (513, 512)):
+        blocks, grid = ramped_blocks(n, b)
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(a[1] == c[0] for a, c in zip(blocks, blocks[1:]))
+        assert all(hi > lo for lo, hi in blocks)
+        assert all(lo % grid == 0 for lo, _ in blocks) and all((hi - lo) % grid == 0 for lo, hi in blocks[:-1])
+        assert max(hi - lo for lo, hi in blocks) <= b + grid
+        if n > b and b // 8 >= 16:
+            assert blocks[0][1] - blocks[0][0] == grid == b // 8 and blocks[-1][1] - blocks[-1][0] < 2 * grid
