@@ -1632,6 +1632,7 @@ TrainDims train_dims(const gpdla_training *t, int k) {
     d.GS = gs;
   }
   d.H = (int32_t)std::max<int64_t>(d.H, (d.PG + kTrBuildMaxChunks - 1) / kTrBuildMaxChunks);  // a split's omega2 table fits its LDS
+  d.GS = (d.GS + 3) / 4 * 4;  // k_train_core_wide: four splits per block
   return d;
 }
 
@@ -1702,8 +1703,9 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
     if (ly) hipLaunchKernelGGL(k_train_core<true>, core_grid, dim3(256), kTrCoreLds, st, co);
     else hipLaunchKernelGGL(k_train_core<false>, core_grid, dim3(256), kTrCoreLds, st, co);
   } else {
-    if (ly) hipLaunchKernelGGL(k_train_core_wide<true>, core_grid, dim3(256), 0, st, co);
-    else hipLaunchKernelGGL(k_train_core_wide<false>, core_grid, dim3(256), 0, st, co);
+    const dim3 wide_grid((unsigned)(d.PG * (d.GS / 4)));  // one pixel group per block, four splits (train_dims keeps GS % 4 == 0)
+    if (ly) hipLaunchKernelGGL(k_train_core_wide<true>, wide_grid, dim3(256), 0, st, co);
+    else hipLaunchKernelGGL(k_train_core_wide<false>, wide_grid, dim3(256), 0, st, co);
   }
   TrainContractArgs ca;  // dM: rows = pixels, steps over quasars
   ca.Aw = t->d_wB;

@@ -909,53 +909,109 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
 }
 
-// 20 < k <= 40: 216 column steps -- too many B operands for the registers and 110 KB of A operands
-// per quasar group -- so both operands of every MFMA come straight from global memory (512
-// contiguous bytes per wave and step, L2 / MALL resident: recE is 34 MB for 5000 quasars), four
-// accumulator chains.  One wave per (pixel group, split); no LDS operands, no barriers in the loop.
+// 20 < k <= 40: 216 column steps -- too many operands for the registers (432 per lane) and 110 KB per
+// quasar group, twice that per block: too many for LDS as well.  A block is ONE pixel group and four
+// consecutive splits of the quasar groups (one per wave): the pixel group's operand -- the same for
+// the four waves -- is staged through LDS in chunks of 12 column steps (6 KiB, double-buffered by
+// the asynchronous copy, one barrier per chunk), each wave's own quasar-group operand comes straight
+// from L2 into registers one chunk ahead (two register sets, the chunk loop unrolled by two), four
+// accumulator chains.  (Round 3 first streamed BOTH operands of every MFMA from L2: 5.3 GB per
+// evaluation through L2, latency-bound at 7.6 TB/s, 0.72-0.78 ms.)  The waves of a block run the same
+// number of chunks -- a split that has one quasar group fewer idles through the last ones.
+constexpr int kTrWideCH = 12;
 template <bool LY>
-__global__ __launch_bounds__(256) void k_train_core_wide(TrainCoreArgs a) {
+__global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
   using K = TrC<40>;
+  constexpr int CH = kTrWideCH, NCH = K::Ks / CH;
+  static_assert(K::Ks % CH == 0 && (CH * 64) % 128 == 0 && CH % 4 == 0, "whole chunks of whole KiB");
+  static_assert(K::KsW > (NCH - 1) * CH, "only the last chunk mixes X and Y steps");
+  __shared__ __attribute__((aligned(16))) double sB[2][CH * 64];
+  __shared__ double T_s[kTrMaxLines + 1];
   const TrainDims &D = a.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t pblk = blockIdx.x / D.GS;
-  const int gs = (int)(blockIdx.x % D.GS);
-  const int64_t pt = pblk * 4 + wave;
+  const int64_t pt = blockIdx.x / (D.GS / 4);  // (grid: PG x GS / 4 blocks; GS is a multiple of 4)
+  const int gs4 = (int)(blockIdx.x % (D.GS / 4)) * 4, gs = gs4 + wave;
   const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;
+  int iters = 0;  // block-uniform: the longest of the four splits
+  for (int w = 0; w < 4; ++w)
+    iters = max(iters, (int)((D.NQ16 * (gs4 + w + 1)) / D.GS - (D.NQ16 * (gs4 + w)) / D.GS));
+  const int total = iters * NCH;
   const int jj = lane >> 4, s = lane & 15;
   const int64_t p = pt * 16 + s;
   const TrainScal sc = train_scal(a.x, D.G, D.k);
   const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
-  __shared__ double T_s[kTrMaxLines + 1];
-  if (LY) {
-    if (threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);
-    __syncthreads();
-  }
-  if (pt >= D.PG) return;
+  if (LY && threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);  // (published by the first chunk's barrier)
   const double om = p < D.G ? train_omega2(a.x, D.G, D.k, p) : 0.0;
   const int64_t ob = pt * D.TQ * 64 + lane;
-  const double *bp = a.recP + pt * K::Ks * 64 + lane;
+  const double *bsrc = a.recP + pt * K::Ks * 64;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const uint32_t sB_lds = __builtin_amdgcn_readfirstlane(lds_address(&sB[0][0]));
+  auto issue = [&](int n) {  // running chunk n: chunk n % NCH of the pixel group's operand into buffer n & 1
+    glds_chunk<CH * 64 / 128, 4>(bsrc + (size_t)(n % NCH) * CH * 64, sB_lds + (uint32_t)(n & 1) * (uint32_t)(CH * 64 * 8), wave_s,
+                                 lane);
+  };
+  auto group_of = [&](int it) -> int64_t {  // (an idle iteration re-reads the split's last group; nothing of it is used)
+    return min(max(min(g0 + it, g1 - 1), (int64_t)0), D.NQ16 - 1);
+  };
+  auto load_a = [&](int n, double (&dst)[CH]) {
+    const int it = n / NCH, c = n - it * NCH;
+    const double *re = a.recE + group_of(it) * K::Ks * 64 + (size_t)c * CH * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) dst[j] = re[j * 64];
+  };
+  double A0[CH], A1[CH];
+  if (total > 0) {
+    issue(0);
+    load_a(0, A0);
+  }
   double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
-  for (int64_t g = g0; g < g1; ++g) {
-    const double *re = a.recE + g * K::Ks * 64 + lane;
-    TrainCoreRaw raw;
-    train_core_load<LY>(a, g, p, jj, true, raw);
-    __builtin_amdgcn_sched_barrier(0);
-    d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, x2 = x0, x3 = x0, yv = x0;
-    for (int ks = 0; ks + 3 < K::KsW; ks += 4) {
-      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], x0, 0, 0, 0);
-      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 1) * 64], bp[(ks + 1) * 64], x1, 0, 0, 0);
-      x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 2) * 64], bp[(ks + 2) * 64], x2, 0, 0, 0);
-      x3 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[(ks + 3) * 64], bp[(ks + 3) * 64], x3, 0, 0, 0);
+  d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, x2 = x0, x3 = x0, yv = x0;
+  TrainCoreRaw raw;
+  auto phase = [&](int n, const double (&cur)[CH], double (&nxt)[CH]) {
+    const int it = n / NCH, c = n - it * NCH;
+    const bool live = g0 + it < g1;
+    glds_wait();      // chunk n of the shared operand landed (this wave's part); so did cur
+    __syncthreads();  // ... everyone's; the other buffer's readers are done
+    if (n + 1 < total) {
+      issue(n + 1);
+      load_a(n + 1, nxt);
     }
-    for (int ks = K::KsW & ~3; ks < K::KsW; ++ks)
-      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], x0, 0, 0, 0);
-    for (int ks = K::KsW; ks < K::Ks; ++ks)
-      yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bp[ks * 64], yv, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
-                   (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
-    train_core_tile<LY>(a, g, raw, jj, true, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
+    if (c == 0) {
+      x0 = x1 = x2 = x3 = yv = d4{0.0, 0.0, 0.0, 0.0};
+      train_core_load<LY>(a, group_of(it), p, jj, true, raw);  // used behind this group's chunks
+    }
+    const double *b = &sB[n & 1][0] + lane;
+    if (c < NCH - 1) {
+#pragma unroll
+      for (int j = 0; j < CH; j += 4) {
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], b[j * 64], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j + 1], b[(j + 1) * 64], x1, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j + 2], b[(j + 2) * 64], x2, 0, 0, 0);
+        x3 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j + 3], b[(j + 3) * 64], x3, 0, 0, 0);
+        if (j % 8 == 4) __builtin_amdgcn_sched_barrier(0);  // (at most eight LDS operands requested ahead: registers)
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        constexpr int ks0 = (NCH - 1) * CH;
+        if (ks0 + j < K::KsW) {  // compile-time
+          d4 &x = (j & 3) == 0 ? x0 : (j & 3) == 1 ? x1 : (j & 3) == 2 ? x2 : x3;
+          x = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], b[j * 64], x, 0, 0, 0);
+        } else {
+          yv = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], b[j * 64], yv, 0, 0, 0);
+        }
+        if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (live) {
+        const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
+                       (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
+        train_core_tile<LY>(a, g0 + it, raw, jj, true, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
+      }
+    }
+  };
+  for (int n = 0; n < total; n += 2) {
+    phase(n, A0, A1);
+    if (n + 1 < total) phase(n + 1, A1, A0);
   }
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
 }
