@@ -521,11 +521,18 @@ struct TrainFactorArgs {
 
 // Geometry of k_train_factor: a wave factors QW quasars side by side (sub-group sg of KMAX lanes,
 // lane i of it owns row i), a block is 4 waves.
+// L and L^-1 are lower triangular and are stored packed, rows padded to an even length so that every
+// row starts on a 16-byte boundary (two entries per LDS read): rows 2m and 2m+1 take 2m + 2 doubles
+// each.  Half the LDS of a dense KMAX x KMAX array: two blocks per CU for k <= 40 too.
+__host__ __device__ constexpr int tri_off(int r) { return 2 * (r / 2) * (r / 2 + 1) + (r & 1) * (2 * (r / 2) + 2); }
+__host__ __device__ constexpr int tri_len(int r) { return 2 * (r / 2) + 2; }  // padded length of row r (>= r + 1)
 template <int KMAX> struct TrF {
   static constexpr int QW = 64 / KMAX;  // 3 (k <= 20), 1 (k <= 40)
   static constexpr int Waves = 4;
   static constexpr int FQ = QW * Waves;  // quasars per block: a whole number of quasar steps of recD
   static_assert(FQ % 4 == 0, "a block writes whole quasar steps of recD");
+  // doubles of L / L^-1 per quasar; the recE rows (4 Ks) are assembled in the same storage afterwards
+  static constexpr int LSize = tri_off(KMAX) > 4 * TrC<KMAX>::Ks ? tri_off(KMAX) : 4 * TrC<KMAX>::Ks;
 };
 
 // Orders the LDS traffic of ONE wave: lanes exchange data through LDS without a block barrier (a
@@ -537,7 +544,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(256) void k_train_factor(TrainFactorArgs a) {
+__global__ __launch_bounds__(256, 2) void k_train_factor(TrainFactorArgs a) {
   // Lane i of a sub-group owns row i of B / L in registers (static indices: every loop over KMAX
   // is unrolled; no private array is indexed at run time -- that would live in scratch memory).
   // Ranks below KMAX are padded with identity rows (B = I there: L = I, log L_jj = 0, z = 0), so
@@ -550,13 +557,12 @@ __global__ __launch_bounds__(256) void k_train_factor(TrainFactorArgs a) {
   using K = TrC<KMAX>;
   using F = TrF<KMAX>;
   constexpr int FQ = F::FQ, QW = F::QW;
-  __shared__ __attribute__((aligned(16))) double s_L[FQ][KMAX * KMAX];
+  __shared__ __attribute__((aligned(16))) double s_L[FQ][F::LSize];
   __shared__ __attribute__((aligned(16))) double s_S[FQ][K::Cols];
   __shared__ __attribute__((aligned(16))) double s_t[FQ][KMAX], s_z[FQ][KMAX], s_ld[FQ][KMAX], s_col[F::Waves][64];
   __shared__ double s_sc[FQ][4];
   __shared__ int s_good[FQ];
   __shared__ uint8_t s_vi[K::W * 16], s_vj[K::W * 16];
-  static_assert(K::Ks * 4 <= KMAX * KMAX, "recE rows must fit the storage of L");
   static_assert(4 * K::KsW <= 16 * K::W && 4 * K::KsU <= 16 * K::U, "recE columns are a prefix of recD's");
   const TrainDims &D = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = D.k;
@@ -638,7 +644,8 @@ __global__ __launch_bounds__(256) void k_train_factor(TrainFactorArgs a) {
   }
   if (valid) {
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j) sL[i * KMAX + j] = j <= i ? row[j] : 0.0;
+    for (int j = 0; j < KMAX; ++j)
+      if (j < tri_len(i)) sL[tri_off(i) + j] = j <= i ? row[j] : 0.0;  // (the pad entry of an even row: 0)
     st[i] = tl;
     s_ld[ql][i] = log(my_l);
   }
@@ -650,17 +657,18 @@ __global__ __launch_bounds__(256) void k_train_factor(TrainFactorArgs a) {
     double s0 = r == i ? 1.0 : 0.0, s1 = 0.0;  // two chains: the dot product is latency-, not throughput-bound
 #pragma unroll
     for (int mm = 0; mm + 1 < r; mm += 2) {  // broadcast reads, two entries at a time
-      const double2 lp = *reinterpret_cast<const double2 *>(sL + r * KMAX + mm);
+      const double2 lp = *reinterpret_cast<const double2 *>(sL + tri_off(r) + mm);
       s0 = fma(-lp.x, x[mm], s0);
       s1 = fma(-lp.y, x[mm + 1], s1);
     }
-    if (r & 1) s0 = fma(-sL[r * KMAX + r - 1], x[r - 1], s0);
+    if (r & 1) s0 = fma(-sL[tri_off(r) + r - 1], x[r - 1], s0);
     x[r] = r >= i ? (s0 + s1) * dinv[r] : 0.0;
   }
   wave_lds_sync();  // every lane has read L: its storage now takes L^-1
   if (valid) {
 #pragma unroll
-    for (int r = 0; r < KMAX; ++r) sL[r * KMAX + i] = x[r];
+    for (int r = 0; r < KMAX; ++r)
+      if (i < tri_len(r)) sL[tri_off(r) + i] = x[r];  // (x_r = 0 for r < i: the pad entry is 0)
   }
   wave_lds_sync();
   // B^-1 = L^-T L^-1: entry (i, c) = Sum_{r >= max(i, c)} Linv[r][i] Linv[r][c]; z = B^-1 t on the way
@@ -669,13 +677,15 @@ __global__ __launch_bounds__(256) void k_train_factor(TrainFactorArgs a) {
   for (int c0 = 0; c0 < KMAX; c0 += 4) {
     double v[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = c0; r < KMAX; ++r) {  // Linv[r][c] = 0 for c > r (stored zeros)
-      const double2 l0 = *reinterpret_cast<const double2 *>(sL + r * KMAX + c0);
-      const double2 l1 = *reinterpret_cast<const double2 *>(sL + r * KMAX + c0 + 2);
+    for (int r = c0; r < KMAX; ++r) {  // Linv[r][c] = 0 for c > r: rows c0, c0 + 1 end at column c0 + 1
+      const double2 l0 = *reinterpret_cast<const double2 *>(sL + tri_off(r) + c0);
       v[0] = fma(x[r], l0.x, v[0]);
       v[1] = fma(x[r], l0.y, v[1]);
-      v[2] = fma(x[r], l1.x, v[2]);
-      v[3] = fma(x[r], l1.y, v[3]);
+      if (r >= c0 + 2) {  // compile-time
+        const double2 l1 = *reinterpret_cast<const double2 *>(sL + tri_off(r) + c0 + 2);
+        v[2] = fma(x[r], l1.x, v[2]);
+        v[3] = fma(x[r], l1.y, v[3]);
+      }
     }
     const double2 t0 = *reinterpret_cast<const double2 *>(st + c0), t1 = *reinterpret_cast<const double2 *>(st + c0 + 2);
     zacc = fma(v[0], t0.x, zacc);

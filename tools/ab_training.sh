@@ -9,7 +9,7 @@ for so in build/ab/*.so; do
   d=gpurun_out/abtr_$name
   rm -rf $d && mkdir -p $d
   GPDLA_LIB_PATH=$PWD/$so rocprofv3 --kernel-trace --stats --output-format csv -d $d -o tr -- python3 tools/bench_training.py --k $K > $d/bench.log 2>&1 || { echo "$name FAILED"; tail -3 $d/bench.log; continue; }
-  echo "== $name: $(python3 -c "import json,sys; print(round(1e3*json.loads(open('$d/bench.log').readline())['gpu_seconds_per_eval'],4))") ms/eval (under the profiler)"
+  echo "== $name: $(grep '^{"metric"' $d/bench.log | tail -1 | python3 -c "import json,sys; print(round(1e3*json.loads(sys.stdin.readline())['gpu_seconds_per_eval'],4))") ms/eval (under the profiler)"
   python3 - "$d" <<'PY'
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
