@@ -325,11 +325,9 @@ class PreloadedReader:
     """Random access to the ragged cell arrays of a ``-v7.3`` preloaded_qsos.mat (preload_qsos.m:64-79):
     the file is opened once, the four reference tables are read, and a rank then dereferences only
     the quasars of its own block -- pixel counts come from the dataset headers alone, so sharding a
-    run by pixel count (distributed.shard_bounds) reads no spectrum.  Rate (this pure-Python reader,
-    one thread): ~8800 quasars/s for contiguous cells, ~3300/s for deflate-compressed ones as MATLAB
-    writes them (30 % of that is zlib, the rest header parsing under the GIL, so threads do not
-    help): a DR12Q shard of 20 358 quasars is ~6 s of reading next to 1.9 s of sweep -- hidden behind
-    the sweep only in part (run_dr12q reads batch i + 1 while batch i is swept).
+    run by pixel count (distributed.shard_bounds) reads no spectrum.  :meth:`read` is the pure-Python
+    reader (one thread: ~4000-11000 quasars/s depending on the host core and on whether the cells
+    are compressed; header parsing under the GIL, so threads do not help).
     :meth:`read_csr` is the fast path: the same cells through csrc/h5cells.c (object headers, chunk
     B-trees and zlib in C, cells spread over threads), straight into the flat arrays a batch
     upload takes; cells outside that reader's subset, or a box without gcc, fall back to the
