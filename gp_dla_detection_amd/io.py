@@ -258,14 +258,14 @@ def load_preloaded_qsos(path: str, z_qsos, test_ind=None) -> list:
         return np.flatnonzero(t) if t.dtype == bool else t
 
     if _is_hdf5(path):
-        with hdf5.File(path) as f:
-            refs = {}
-            for k in keys:
-                if k not in f:
-                    raise KeyError(f"{path} lacks {k}")
-                refs[k] = f[k].read().T.ravel(order="F")
-            idx = pick(refs[keys[0]].size)
-            cells = {k: [_from_dataset(f, f.dereference(refs[k][i])) for i in idx] for k in keys}
+        # the native cell reader where it applies (PreloadedReader.read_csr), split back into per-quasar views
+        with PreloadedReader(path) as r:
+            idx = pick(r.num_quasars)
+            csr = r.read_csr(idx, z)
+        o = csr["offsets"]
+        return [dict(wavelengths=csr["wavelengths"][o[j]:o[j + 1]], flux=csr["flux"][o[j]:o[j + 1]],
+                     noise_variance=csr["noise_variance"][o[j]:o[j + 1]], pixel_mask=csr["pixel_mask"][o[j]:o[j + 1]],
+                     z_qso=float(z[i])) for j, i in enumerate(idx)]
     else:
         m = _load_mat(path, keys)
         idx = pick(len(m["all_wavelengths"]))
