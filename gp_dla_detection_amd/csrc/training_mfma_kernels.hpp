@@ -152,11 +152,14 @@ __global__ void k_train_lines(TrainLinesArgs a) {
 
 // (log(1+z) is data: it is taken once, when the training set is uploaded, so that the power of
 // spectrum_loss.m:22 costs one exp per evaluation instead of a pow)
-// (tau_0: the pixel's line scale T[n] -- tau_0 itself for the plain objective)
+// (tau_0: the pixel's line scale T[n] -- tau_0 itself for the plain objective; beta64 = beta * 64 / ln 2:
+// both exponentials go through the sweep's 64-entry table (exp_table_scaled, relative error < 2e-16),
+// 11 instructions each where a series in full costs 20, and the power needs no reciprocal)
 __device__ __forceinline__ void train_element(double y, double logz1, double nu, double om, double c_0,
-                                              double tau_0, double beta, double *w, double *u, double *d_out) {
-  const double od = tau_0 * fast_rcp(exp_nonpos(-beta * logz1));  // spectrum_loss.m:22: tau0 (1+z)^beta
-  const double sf = 1 - exp_nonpos(-od) + c_0;  // :23, :26
+                                              double tau_0, double beta64, const double *exp_tab, double *w,
+                                              double *u, double *d_out) {
+  const double od = tau_0 * exp_table_scaled(beta64 * logz1, exp_tab);  // spectrum_loss.m:22: tau0 (1+z)^beta
+  const double sf = 1 - exp_table_scaled(-kExpScale * od, exp_tab) + c_0;  // :23, :26
   const double d = nu + om * (sf * sf);         // :27, :29
   *w = fast_rcp(d);                             // :31
   *u = *w * y;                                // :32
@@ -242,7 +245,7 @@ constexpr int kTrChunk = 4;                             // steps per staged chun
 constexpr int kTrCWaves = 4;                            // row groups (waves) per block
 constexpr size_t kTrContractLds = 2 * kTrChunk * kTrGroupD * sizeof(double);  // 64 KiB
 constexpr int kTrBuildMaxChunks = 64;  // chunks of one split of k_train_build (its omega2 table: 8 KiB)
-constexpr size_t kTrBuildLds = kTrContractLds + (16 * kTrBuildMaxChunks + kTrMaxLines + 1) * sizeof(double);  // + the line table
+constexpr size_t kTrBuildLds = kTrContractLds + (16 * kTrBuildMaxChunks + kTrMaxLines + 1 + 64) * sizeof(double);  // + the line table + the exp table
 
 // NW: tiles of the block's group that take a_w (compile-time: the A operand of every MFMA is then
 // a fixed register, not a select)
@@ -398,6 +401,9 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
   for (int e = threadIdx.x; e < 16 * nchunks; e += kTrCWaves * 64) om_s[e] = a.omega2[16 * c0 + e];
   constexpr bool lyseries = LY;
   double *T_s = om_s + 16 * kTrBuildMaxChunks;
+  double *exp_tab = T_s + kTrMaxLines + 1;  // 2^(j/64)
+  if (threadIdx.x < kExpTab) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / kExpTab));
+  const double beta64 = sc.beta * kExpScale;
   if (lyseries && threadIdx.x == 0) train_line_table(a.lines, sc.tau_0, sc.beta, T_s);
   const uint32_t *pl = reinterpret_cast<const uint32_t *>(a.nl + (lyseries ? row : 0));
   // The raw elements are NOT double-buffered (the registers are needed for two waves per SIMD):
@@ -426,7 +432,7 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
   auto element = [&](double y, double lz, double nv, double om, uint32_t n_lines, double &w, double &u) {
     const bool ok = qreal && !isnan(y);  // rows behind the last quasar and padded / missing pixels
     double d;
-    train_element(y, lz, nv, om, sc.c_0, lyseries ? T_s[n_lines] : sc.tau_0, sc.beta, &w, &u, &d);
+    train_element(y, lz, nv, om, sc.c_0, lyseries ? T_s[n_lines] : sc.tau_0, beta64, exp_tab, &w, &u, &d);
     w = ok ? w : 0.0;
     u = ok ? u : 0.0;
     yy += ok ? y * u : 0.0;
@@ -796,17 +802,18 @@ __device__ __forceinline__ void train_core_load(const TrainCoreArgs &a, int64_t 
 template <bool LY>
 __device__ __forceinline__ void train_core_tile(const TrainCoreArgs &a, int64_t g, const TrainCoreRaw &raw, int jj, bool active, int64_t ob,
                                                 double om, double c_0, double tau_0, double beta, const double *T_s,
-                                                const d4 &X4, const d4 &Y4, double &col, double &gc, double &gt,
-                                                double &gb) {
+                                                const double *exp_tab, const d4 &X4, const d4 &Y4, double &col,
+                                                double &gc, double &gt, double &gb) {
   const double *ye = raw.ye, *lz = raw.lz, *nv = raw.nv;
+  const double beta64 = beta * kExpScale;
   constexpr bool lyseries = LY;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const double y = ye[rr];
     double w = 0.0, u = 0.0;
     if (!isnan(y) && active && g * 16 + jj + 4 * rr < a.d.nq) {
-      const double od = (lyseries ? T_s[raw.nl[rr]] : tau_0) * fast_rcp(exp_nonpos(-beta * lz[rr]));  // :22 (as k_train_build)
-      const double ab = exp_nonpos(-od);                        // :23
+      const double od = (lyseries ? T_s[raw.nl[rr]] : tau_0) * exp_table_scaled(beta64 * lz[rr], exp_tab);  // :22 (as k_train_build)
+      const double ab = exp_table_scaled(-kExpScale * od, exp_tab);  // :23
       const double sf = 1 - ab + c_0;                           // :26
       const double an = om * (sf * sf);                         // :27
       w = fast_rcp(nv[rr] + an);                                // :29-31
@@ -868,8 +875,9 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
   const int64_t p = pt * 16 + s;
   const TrainScal sc = train_scal(a.x, D.G, D.k);
   const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
-  __shared__ double T_s[kTrMaxLines + 1];
+  __shared__ double T_s[kTrMaxLines + 1], exp_tab[kExpTab];
   if (LY && threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);  // (published by the first group's barrier)
+  if (threadIdx.x < kExpTab) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / kExpTab));
   double bP[K::Ks];
 #pragma unroll
   for (int ks = 0; ks < K::Ks; ++ks) bP[ks] = active ? a.recP[(pt * K::Ks + ks) * 64 + lane] : 0.0;
@@ -913,7 +921,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
       yv = __builtin_amdgcn_mfma_f64_16x16x4f64(re[ks * 64], bP[ks], yv, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     const d4 xs = {x0[0] + x1[0], x0[1] + x1[1], x0[2] + x1[2], x0[3] + x1[3]};
-    train_core_tile<LY>(a, g, raw, jj, active, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
+    train_core_tile<LY>(a, g, raw, jj, active, ob, om, c_0, tau_0, beta, T_s, exp_tab, xs, yv, col, gc, gt, gb);
   }
   if (!active) return;
   train_core_store(a, pt, gs, lane, col, gc, gt, gb);
@@ -936,7 +944,8 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
   static_assert(K::Ks % CH == 0 && (CH * 64) % 128 == 0 && CH % 4 == 0, "whole chunks of whole KiB");
   static_assert(K::KsW > (NCH - 1) * CH, "only the last chunk mixes X and Y steps");
   __shared__ __attribute__((aligned(16))) double sB[2][CH * 64];
-  __shared__ double T_s[kTrMaxLines + 1];
+  __shared__ double T_s[kTrMaxLines + 1], exp_tab[kExpTab];
+  if (threadIdx.x < kExpTab) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / kExpTab));  // (published by the first chunk's barrier)
   const TrainDims &D = a.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t pt = blockIdx.x / (D.GS / 4);  // (grid: PG x GS / 4 blocks; GS is a multiple of 4)
@@ -1015,7 +1024,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
       if (live) {
         const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
                        (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
-        train_core_tile<LY>(a, g0 + it, raw, jj, true, ob, om, c_0, tau_0, beta, T_s, xs, yv, col, gc, gt, gb);
+        train_core_tile<LY>(a, g0 + it, raw, jj, true, ob, om, c_0, tau_0, beta, T_s, exp_tab, xs, yv, col, gc, gt, gb);
       }
     }
   };
