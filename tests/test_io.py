@@ -219,3 +219,31 @@ def test_native_cell_reader_equals_the_python_reader(tmp_path, monkeypatch):
                 assert a.dtype == b.dtype and a.shape == b.shape, k
                 np.testing.assert_array_equal(a, b, err_msg=k)
             monkeypatch.setattr(io, "_h5cells", None)
+
+
+def test_streamed_processed_writer_refuses_misuse(tmp_path):
+    """io.ProcessedStreamWriter: batches must sit on the chunk grid (any multiple of it, the last one
+    ragged), may arrive in any order, and finish() refuses an incomplete run."""
+    from gp_dla_detection_amd.api import Batch
+    nq, S, B = 21, 12, 4
+    res = Batch.empty_results(nq, S)
+    res["sample_log_likelihoods_dla"][...] = np.arange(nq * S, dtype=np.float64).reshape(nq, S)
+    for k, v in res.items():
+        if isinstance(v, np.ndarray) and v.dtype == np.float64 and k != "sample_log_likelihoods_dla":
+            v[...] = 1.0
+    res.update(num_lines=3, prior_z_qso_increase=0.1, max_z_cut=0.1)
+    tab = lambda lo, hi: {"sample_log_likelihoods_dla": res["sample_log_likelihoods_dla"][lo:hi]}  # noqa: E731
+    w = io.ProcessedStreamWriter(str(tmp_path / "a.mat"), nq, S, B)
+    with pytest.raises(ValueError):
+        w.append(2, tab(2, 6))          # not on the grid
+    with pytest.raises(ValueError):
+        w.append(0, tab(0, 6))          # not a multiple of the grid (and not the last batch)
+    w.append(12, tab(12, 21))           # two chunk columns and the ragged last one, out of order
+    w.append(0, tab(0, 12))             # three chunk columns
+    w.finish(res, test_set_name="t")
+    got = io.load_processed_qsos(str(tmp_path / "a.mat"))
+    np.testing.assert_array_equal(got["sample_log_likelihoods_dla"], res["sample_log_likelihoods_dla"])
+    w = io.ProcessedStreamWriter(str(tmp_path / "b.mat"), nq, S, B)
+    w.append(0, tab(0, 8))
+    with pytest.raises(ValueError):
+        w.finish(res, test_set_name="t")   # 13 quasars never arrived
