@@ -377,7 +377,8 @@ def main():
                          "measured on this libgpdla.so and workload)",
                          "kernel": ("k_sweep_slim" if args.k <= 20 and args.contraction == "f64"
                                     and not os.environ.get("GPDLA_EXPANDED_RECORDS") else
-                                    "k_sweep_split" if args.k > 20 and args.contraction == "f64" else "k_sweep"),
+                                    ("k_sweep_split" if os.environ.get("GPDLA_EXPANDED_RECORDS") else "k_sweep_split_slim")
+                                    if args.k > 20 and args.contraction == "f64" else "k_sweep"),
                          "kernel_ms": sweep_ms,
                          "flops_per_launch": flops,
                          "flops_per_eval": algorithmic_flops(float(n_kept.mean()), args.k)},

@@ -109,6 +109,7 @@ SYMBOLS = [
     ("gpdla_context_set_model", C.c_int, [C.c_void_p, C.POINTER(Model)]),
     ("gpdla_context_set_samples", C.c_int, [C.c_void_p, C.POINTER(Samples)]),
     ("gpdla_context_set_config", C.c_int, [C.c_void_p, C.POINTER(Config)]),
+    ("gpdla_context_set_first_quasar_index", C.c_int, [C.c_void_p, C.c_int64]),
     ("gpdla_context_synchronize", C.c_int, [C.c_void_p]),
     ("gpdla_batch_upload", C.c_int, [C.c_void_p, C.POINTER(Spectra), C.POINTER(C.c_void_p)]),
     ("gpdla_batch_reload", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Spectra)]),

@@ -215,10 +215,17 @@ class Context:
         return Batch(self, spectra, log_priors_no_dla, log_priors_dla, log_priors_lls)
 
     def set_params(self, params: Parameters):
-        """Replace the configuration (e.g. ``first_quasar_index`` between shards)."""
+        """Replace the whole configuration.  Not while another thread uploads a batch of this
+        context (the upload reads it): a pipeline sets the per-batch key of the multi-DLA resampling
+        with :meth:`set_first_quasar_index` instead."""
         self.params = params
         cfg = _config(params)
         _lib.check(self.lib.gpdla_context_set_config(self._h, C.byref(cfg)))
+
+    def set_first_quasar_index(self, index: int):
+        """The global index of the next multi-DLA batch's first quasar (keys the Philox resampling,
+        multi :467-472).  Safe beside a concurrent upload (gpdla_context_set_first_quasar_index)."""
+        _lib.check(self.lib.gpdla_context_set_first_quasar_index(self._h, int(index)))
 
     def close(self):
         if self._h:
@@ -632,7 +639,6 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
     long list is swept in HBM-resident batches of at most ``max_quasars_per_batch``.
     Returns the variables the script saves (:498-510); 3-D arrays are
     ``sample_log_likelihoods_dla [nq, max_dlas, S]`` and ``MAP_* [nq, model, slot]``."""
-    from dataclasses import replace
     p = params or MultiParameters()
     md = p.max_dlas
     S = np.asarray(samples["offset_samples"]).size
@@ -661,7 +667,7 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
 
     def process(i, batch):
         lo, hi = blocks[i]
-        ctx.set_params(replace(p, first_quasar_index=p.first_quasar_index + lo))
+        ctx.set_first_quasar_index(p.first_quasar_index + lo)
         batch.process_multi(None if base_sample_inds is None else base_sample_inds[lo:hi])
 
     try:

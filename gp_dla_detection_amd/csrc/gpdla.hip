@@ -20,6 +20,7 @@
 #include "multi_kernels.hpp"
 #include "sweep_slim_kernel.hpp"
 #include "sweep_split_kernel.hpp"
+#include "sweep_split_slim_kernel.hpp"
 #include "training_kernels.hpp"
 #include "training_mfma_kernels.hpp"
 
@@ -360,6 +361,12 @@ int gpdla_context_set_config(gpdla_context *c, const gpdla_config *cfg) {
   if (cfg->contraction_precision != 0 && cfg->contraction_precision != 1)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "contraction_precision must be 0 (fp64) or 1 (fp32 study)");
   c->cfg = *cfg;
+  return GPDLA_OK;
+}
+
+int gpdla_context_set_first_quasar_index(gpdla_context *c, int64_t first_quasar_index) {
+  if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
+  c->cfg.first_quasar_index = first_quasar_index;  // (no upload path reads this field)
   return GPDLA_OK;
 }
 
@@ -755,6 +762,30 @@ int launch_sweep_split(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   return GPDLA_OK;
 }
 
+// k_sweep_split_slim: 20 < k <= 40 in fp64 on slim records (tile split over eight waves, B operands
+// formed in registers)
+template <int LINES>
+int launch_sweep_split_slim(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
+  const size_t loop_doubles = sweep_split_slim_lds_doubles(false, LINES > 0 ? 0 : args.num_lines);
+  using ES = EpilogueShape<52, 4>;
+  const size_t epi_doubles = kExpTab + (size_t)2 * ES::SPP * ES::stride(56);
+  const size_t lds = std::max(loop_doubles, epi_doubles) * sizeof(double);
+  if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "split sweep needs %zu B of LDS", lds);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_split_slim<LINES, 0, SweepArgs>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.blocks_per_quasar = (int32_t)((b->S + 1 + 2 * kSamplesPerWave - 1) / (2 * kSamplesPerWave));
+  const int64_t nblocks = 8 * ((args.nq + 7) / 8) * (int64_t)args.blocks_per_quasar;
+  if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "batch too large for one launch");
+  if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL((k_sweep_split_slim<LINES, 0, SweepArgs>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  HIP_TRY(hipGetLastError());
+  if (c->timing) {
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->have_timing = true;
+  }
+  return GPDLA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -836,9 +867,15 @@ int launch_prepare(gpdla_context *c, gpdla_batch *b, bool multi) {
   return GPDLA_OK;
 }
 
-// The K-step records of the quasars h_order[g0 .. g1) into the pool.  slim: the 896-byte records of
-// k_sweep_slim instead of the pre-expanded MFMA tiles.
-int launch_build_records(gpdla_context *c, gpdla_batch *b, int64_t g0, int64_t g1, bool f32_tiles, bool slim) {
+// The K-step records of the quasars h_order[g0 .. g1) into the pool, in one of three classes:
+// pre-expanded MFMA tiles (k_sweep and the legacy / diagnostic paths), the 896-byte records of the
+// k <= 20 slim sweeps, the 1536-byte records of the k <= 40 slim sweeps.
+enum RecordClass { kRecExpanded = 0, kRecSlim20 = 1, kRecSlim40 = 2 };
+int64_t record_class_doubles(RecordClass rc, int ntiles, bool f32_tiles) {
+  return rc == kRecSlim20 ? kSlimRec : rc == kRecSlim40 ? kS40Rec : record_doubles(ntiles, f32_tiles ? 1 : 0);
+}
+int launch_build_records(gpdla_context *c, gpdla_batch *b, int64_t g0, int64_t g1, bool f32_tiles, RecordClass cls) {
+  const bool slim = cls != kRecExpanded;
   BuildRecordsArgs ba;
   ba.meta = b->d_meta;
   ba.pix = b->d_pix;
@@ -852,8 +889,10 @@ int launch_build_records(gpdla_context *c, gpdla_batch *b, int64_t g0, int64_t g
   ba.f32_tiles = f32_tiles ? 1 : 0;
   ba.order = b->d_order + g0;
   const unsigned grid = (unsigned)((g1 - g0) * ba.blocks_per_quasar);
-  if (slim)
+  if (cls == kRecSlim20)
     hipLaunchKernelGGL(k_build_slim_records, dim3(grid), dim3(256), 0, c->stream, ba);
+  else if (cls == kRecSlim40)
+    hipLaunchKernelGGL(k_build_slim40_records, dim3(grid), dim3(256), 0, c->stream, ba);
   else
     hipLaunchKernelGGL(k_build_records, dim3(grid), dim3(256), 0, c->stream, ba);
   HIP_TRY(hipGetLastError());
@@ -876,9 +915,16 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   // GPDLA_EXPANDED_RECORDS=1 (diagnostic): the pre-expanded records of k_sweep, for A/B timing.
   static const bool expanded = std::getenv("GPDLA_EXPANDED_RECORDS") != nullptr;
   const bool f32 = c->cfg.contraction_precision == 1;
+  // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k_sweep form of 20 < k <= 40 in which every wave of a group
+  // repeats the Voigt/weight arithmetic, for A/B timing against k_sweep_split
+  static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
   const bool slim = b->k <= 20 && num_lines == 3 && !f32 && !expanded;
+  // 20 < k <= 40, fp64: slim records as well (k_sweep_split_slim); GPDLA_EXPANDED_RECORDS=1 keeps
+  // k_sweep_split on the pre-expanded 29-KiB records
+  const bool slim40 = b->k > 20 && !f32 && !expanded && !legacy;
+  const RecordClass cls = slim ? kRecSlim20 : slim40 ? kRecSlim40 : kRecExpanded;
   if (b->k > 40) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d needs %d B tiles (max 56)", b->k, b->ntiles);
-  int rc = plan_records(c, b, slim ? kSlimRec : record_doubles(b->ntiles, 0), false);
+  int rc = plan_records(c, b, record_class_doubles(cls, b->ntiles, false), false);
   if (rc) return rc;
   if ((rc = launch_prepare(c, b, false))) return rc;
 
@@ -909,7 +955,7 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   if (timing) HIP_TRY(hipEventRecord(c->ev0, st));
   c->timing = false;
   for (const auto &g : b->groups) {
-    if ((rc = launch_build_records(c, b, g.first, g.second, f32, slim))) break;
+    if ((rc = launch_build_records(c, b, g.first, g.second, f32, cls))) break;
     sa.order = b->d_order + g.first;
     sa.nq = g.second - g.first;
     if (slim) {
@@ -917,10 +963,9 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
     } else if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
       if (!f32) rc = three ? launch_sweep<double, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
       else rc = three ? launch_sweep<float, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
-    } else if (!f32) {  // 52 w-tiles (<= 820) + 4 u-tiles; fp64: 56 accumulator tiles do not fit one wave -> split over 4 waves
-      // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k_sweep form in which every wave of a group repeats
-      // the Voigt/weight arithmetic, for A/B timing against k_sweep_split
-      static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
+    } else if (slim40) {  // 52 w-tiles (<= 820 columns) + 3 u-tiles split over the 8 waves of a block
+      rc = three ? launch_sweep_split_slim<3>(c, b, sa) : launch_sweep_split_slim<0>(c, b, sa);
+    } else if (!f32) {  // the same tiles pre-expanded in the records, split over the 4 waves of a sample group
       if (legacy)
         rc = three ? launch_sweep<double, 8, 14, 4, 2, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
       else
@@ -1157,6 +1202,32 @@ int launch_sweep_multi_split_nd(gpdla_context *c, SweepMultiArgs args) {
   return GPDLA_OK;
 }
 
+template <int ND>
+int launch_sweep_multi_split_slim_nd(gpdla_context *c, SweepMultiArgs args) {
+  using ES = EpilogueShape<52, 4>;
+  const size_t lds = std::max(sweep_split_slim_lds_doubles(true, 0), kExpTab + (size_t)2 * ES::SPP * ES::stride(56)) * sizeof(double);
+  if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "multi split sweep needs %zu B of LDS", lds);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_split_slim<0, ND, SweepMultiArgs>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.blocks_per_quasar = (int32_t)((args.S + 1 + 2 * kSamplesPerWave - 1) / (2 * kSamplesPerWave));
+  const int64_t nblocks = 8 * (((int64_t)args.nq_sub + 7) / 8) * (int64_t)args.blocks_per_quasar;
+  if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "sub-batch too large for one launch");
+  hipLaunchKernelGGL((k_sweep_split_slim<0, ND, SweepMultiArgs>), dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  HIP_TRY(hipGetLastError());
+  return GPDLA_OK;
+}
+
+// 20 < k <= 40 on slim records (k_sweep_split_slim with gathers in place of the Voigt stages)
+int launch_sweep_multi_split_slim(gpdla_context *c, const SweepMultiArgs &args) {
+  switch (args.mode == 0 ? 1 : args.mode) {
+    case 1: return launch_sweep_multi_split_slim_nd<1>(c, args);
+    case 2: return launch_sweep_multi_split_slim_nd<2>(c, args);
+    case 3: return launch_sweep_multi_split_slim_nd<3>(c, args);
+    case 4: return launch_sweep_multi_split_slim_nd<4>(c, args);
+    default: return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d > 4", args.mode);
+  }
+}
+
 // 20 < k <= 40: the roles of a sample group share the gathers and weights (k_sweep_multi_split)
 int launch_sweep_multi_split(gpdla_context *c, const SweepMultiArgs &args) {
   switch (args.mode == 0 ? 1 : args.mode) {
@@ -1251,9 +1322,14 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, st));
   // (the multi-DLA sweeps walk the batch in profile-table sub-batches of their own: all records
   // are built up front, one group)
-  if ((rc = plan_records(c, b, record_doubles(b->ntiles, 0), true))) return rc;
+  // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k <= 40 form in which every wave of a group gathers and
+  // weighs for itself; GPDLA_EXPANDED_RECORDS=1 (diagnostic): the sweeps on pre-expanded records
+  static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
+  static const bool expanded = std::getenv("GPDLA_EXPANDED_RECORDS") != nullptr;
+  const RecordClass cls = (b->k > 20 && !legacy && !expanded) ? kRecSlim40 : kRecExpanded;
+  if ((rc = plan_records(c, b, record_class_doubles(cls, b->ntiles, false), true))) return rc;
   if ((rc = launch_prepare(c, b, true))) return rc;
-  if ((rc = launch_build_records(c, b, 0, b->nq, false, false))) return rc;
+  if ((rc = launch_build_records(c, b, 0, b->nq, false, cls))) return rc;
   // NaN pre-fill (multi :110-131); alive != 0; base = 0 (multi :116) or the caller's indices
   HIP_TRY(hipMemsetAsync(mb.sll_dla, 0xFF, nqs * md * S * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(mb.sll_lls, 0xFF, nqs * S * sizeof(double), st));
@@ -1312,12 +1388,10 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
         sa.sample_ll_dla = mb.sll_dla;
         sa.sample_ll_lls = mb.sll_lls;
         sa.ll_no_dla = mb.ll_no;
-        // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k <= 40 form in which every wave of a group gathers and
-        // weighs for itself, for A/B timing against k_sweep_multi_split
-        static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
         sa.pix = b->d_pix;
         rc = b->k <= 20 ? launch_sweep_multi<14, 1, 8, 13>(c, b, sa)
-                        : legacy ? launch_sweep_multi<14, 4, 1, 52>(c, b, sa) : launch_sweep_multi_split(c, sa);
+             : legacy ? launch_sweep_multi<14, 4, 1, 52>(c, b, sa)
+             : cls == kRecSlim40 ? launch_sweep_multi_split_slim(c, sa) : launch_sweep_multi_split(c, sa);
         if (rc) return rc;
       }
       // evidence, MAP, early-exit flags for the quasars of this sub-batch

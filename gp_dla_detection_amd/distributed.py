@@ -17,8 +17,6 @@ chunk files.  A rank only needs its own block of spectra: pass a loader instead 
 """
 from __future__ import annotations
 
-from dataclasses import replace
-
 import numpy as np
 
 SUMMARY_COLUMNS = ("min_z_dlas", "max_z_dlas", "log_priors_no_dla", "log_priors_dla",
@@ -77,6 +75,36 @@ def gather_summaries(local_table, counts=None, group=None):
     out = torch.empty((world * width, ncol), dtype=local_table.dtype, device=local_table.device)
     dist.all_gather_into_tensor(out, padded, group=group)
     return torch.cat([out[r * width: r * width + counts[r]] for r in range(world)], dim=0)
+
+
+class ShardFailure(RuntimeError):
+    """Some rank of a sharded run failed; raised on EVERY rank (see :func:`agree_on_failure`)."""
+
+
+def agree_on_failure(error: BaseException | None, group=None, what: str = "sharded run") -> None:
+    """Every rank calls this once its local work is over -- successfully (``error`` None) or not --
+    and BEFORE the collective that needs everybody's results: one all-reduce (MAX) of a failure flag.
+    If any rank failed, every rank raises -- the failing one its own exception, the others
+    :class:`ShardFailure` -- instead of waiting in the gather for a rank that will never arrive
+    (the reference's batch jobs are independent processes, CDDF_analysis/sbatch_reunion.py:13-27:
+    there a failed job simply leaves its chunk missing; ranks of one process group must agree).
+    A rank that dies without reaching this point is covered by the group's ``timeout``."""
+    import torch
+    import torch.distributed as dist
+
+    failed = error is not None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        on_gpu = dist.get_backend(group) != "gloo" and torch.cuda.is_available()
+        flag = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64,
+                            device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        anyone = bool(flag.item() > 0)
+    else:
+        anyone = failed
+    if failed:
+        raise error
+    if anyone:
+        raise ShardFailure(f"{what}: another rank failed; this rank's results are discarded")
 
 
 def summary_to_fields(table) -> dict:
@@ -151,10 +179,17 @@ def run_sharded(bounds, rank, ncol, sweep_block, group=None):
     Returns (gathered table, (lo, hi), local results or None)."""
     import torch
     lo, hi = bounds[rank]
+    error = None
+    table, local = torch.empty((0, ncol), dtype=torch.float64), None
     if hi > lo:
-        table, local = sweep_block(lo, hi)
-    else:
-        table, local = torch.empty((0, ncol), dtype=torch.float64), None
+        try:
+            table, local = sweep_block(lo, hi)
+        except Exception as e:  # agreed on below: no rank is left waiting in the gather
+            error = e
+    if len(bounds) > 1:
+        agree_on_failure(error, group)
+    elif error is not None:
+        raise error
     counts = [b[1] - b[0] for b in bounds]
     if len(bounds) > 1 and hi == lo:  # put the empty table where the other ranks' tables live
         import torch.distributed as dist
@@ -192,19 +227,26 @@ def sweep_block_pipelined(model, samples, block_spectra, priors, params, device,
         b0, b1 = blocks[i]
         return (block_spectra[b0:b1],) + tuple(np.asarray(p)[b0:b1] for p in priors)
 
+    copied = [None] * len(blocks)
+
     def process(i, batch):
         b0, b1 = blocks[i]
         with torch.cuda.stream(stream):
             if multi:
-                ctx.set_params(replace(params, first_quasar_index=first_index + b0))
+                ctx.set_first_quasar_index(first_index + b0)
                 batch.process_multi(None if base_sample_inds is None else np.asarray(base_sample_inds)[b0:b1])
             else:
                 batch.process()
             table[b0:b1].copy_(batch.summary_tensor())
+            # the copy reads the batch's summary rows AFTER the library recorded the batch's own
+            # "done" event: the slot must not be re-filled before it has run (download waits for it)
+            copied[i] = torch.cuda.Event()
+            copied[i].record(stream)
 
     def download(i, batch):
         b0 = blocks[i][0]
         (batch.download_multi(True, local, b0) if multi else batch.download(True, local, b0))
+        copied[i].synchronize()
 
     try:
         ctx.set_model(model)

@@ -38,7 +38,7 @@ typedef enum {
 } gpdla_status;
 
 #define GPDLA_MAX_K 40
-#define GPDLA_ABI_VERSION 4
+#define GPDLA_ABI_VERSION 5
 
 int gpdla_abi_version(void);
 /* Human-readable text of the most recent error on this thread (never NULL). */
@@ -188,6 +188,12 @@ int gpdla_context_set_stream(gpdla_context *ctx, void *hip_stream);
 int gpdla_context_set_model(gpdla_context *ctx, const gpdla_model *model);      /* H2D copy */
 int gpdla_context_set_samples(gpdla_context *ctx, const gpdla_samples *samples);/* H2D copy */
 int gpdla_context_set_config(gpdla_context *ctx, const gpdla_config *config);
+/* Sets config.first_quasar_index alone.  gpdla_context_set_config replaces the whole configuration and
+ * must not run while another thread uploads or re-fills a batch of this context (the upload reads
+ * the configuration); this call touches one field no upload reads, so the thread that launches the
+ * sweeps of a host pipeline may call it per batch while its upload thread is busy (the value is
+ * read by the next gpdla_batch_process_multi on the calling thread). */
+int gpdla_context_set_first_quasar_index(gpdla_context *ctx, int64_t first_quasar_index);
 int gpdla_context_synchronize(gpdla_context *ctx);
 
 /* Copies a CSR batch of spectra to HBM and allocates its result table there.  With

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_typed(lib):
     for n in names:
         assert hasattr(lib, n), f"libgpdla.so does not export {n}"
         assert n in typed, f"{n} has no ctypes signature in _lib.SYMBOLS"
-    assert lib.gpdla_abi_version() == 4
+    assert lib.gpdla_abi_version() == 5
 
 
 def test_struct_layouts_match_header(lib):
