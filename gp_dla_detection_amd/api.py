@@ -447,11 +447,13 @@ class Batch:
 
 def record_bytes_per_quasar(num_pixels: int, k: int, slim: bool = True) -> int:
     """Bytes of K-step records (one per 4 pixels) a quasar of ``num_pixels`` stored pixels needs in
-    the record pool: 896 B per step for k <= 20 (k_sweep_slim: the M rows, pixel rows and
-    wavelengths; ``slim=False``: the 7680-byte pre-expanded records of k_sweep, used for other line
-    counts and the fp32 study), 29 696 B for 20 < k <= 40.  The pool is bounded by
-    ``Parameters.record_pool_bytes`` whatever the batch size (the library sweeps group by group)."""
-    per_step = (896 if slim else 7680) if k <= 20 else 29696
+    the record pool: 896 B per step for k <= 20 (k_sweep_slim / k_sweep_multi_slim: the M rows, pixel
+    rows and wavelengths), 1536 B for 20 < k <= 40 (k_sweep_split_slim: the M rows);
+    ``slim=False``: the pre-expanded records of k_sweep / k_sweep_split -- 7680 B and 29 696 B --
+    used for other line counts at k <= 20, the fp32 study and ``GPDLA_EXPANDED_RECORDS=1``.  The
+    pool of the single-DLA sweep is bounded by ``Parameters.record_pool_bytes`` whatever the batch
+    size (the library sweeps group by group)."""
+    per_step = ((896 if slim else 7680) if k <= 20 else (1536 if slim else 29696))
     return int((num_pixels / 4 + 2) * per_step)
 
 
@@ -470,7 +472,7 @@ def default_batch_size(num_quasars: int, longest: int, k: int, num_samples: int,
     128 so that a launch fills the 256 CUs many times over."""
     per_q = resident_bytes_per_quasar(longest, k, num_samples, multi_models)
     if multi_models:  # the multi-DLA sweeps build all records of a batch up front
-        per_q += record_bytes_per_quasar(longest, k, slim=False)
+        per_q += record_bytes_per_quasar(longest, k)
     cap = max(1, int(budget_bytes / slots / per_q))
     want = max(128, -(-num_quasars // 8))
     return max(1, min(cap, want, 4096))

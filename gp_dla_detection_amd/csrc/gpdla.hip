@@ -18,6 +18,7 @@
 #include "../../include/gpdla.h"
 #include "../../include/gpdla_lyman_series.h"
 #include "multi_kernels.hpp"
+#include "sweep_multi_slim_kernel.hpp"
 #include "sweep_slim_kernel.hpp"
 #include "sweep_split_kernel.hpp"
 #include "sweep_split_slim_kernel.hpp"
@@ -1203,6 +1204,30 @@ int launch_sweep_multi_split_nd(gpdla_context *c, SweepMultiArgs args) {
 }
 
 template <int ND>
+int launch_sweep_multi_slim_nd(gpdla_context *c, SweepMultiArgs args) {
+  const size_t lds = sweep_multi_slim_lds_doubles() * sizeof(double);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_multi_slim<ND>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  args.blocks_per_quasar = (int32_t)((args.S + 1 + kSweepWaves * kSamplesPerWave - 1) / (kSweepWaves * kSamplesPerWave));
+  const int64_t nblocks = 8 * (((int64_t)args.nq_sub + 7) / 8) * (int64_t)args.blocks_per_quasar;
+  if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "sub-batch too large for one launch");
+  hipLaunchKernelGGL(k_sweep_multi_slim<ND>, dim3((unsigned)nblocks), dim3(512), lds, c->stream, args);
+  HIP_TRY(hipGetLastError());
+  return GPDLA_OK;
+}
+
+// k <= 20 on slim records (k_sweep_multi with k_sweep_slim's in-sweep vech expansion)
+int launch_sweep_multi_slim(gpdla_context *c, const SweepMultiArgs &args) {
+  switch (args.mode == 0 ? 1 : args.mode) {
+    case 1: return launch_sweep_multi_slim_nd<1>(c, args);
+    case 2: return launch_sweep_multi_slim_nd<2>(c, args);
+    case 3: return launch_sweep_multi_slim_nd<3>(c, args);
+    case 4: return launch_sweep_multi_slim_nd<4>(c, args);
+    default: return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d > 4", args.mode);
+  }
+}
+
+template <int ND>
 int launch_sweep_multi_split_slim_nd(gpdla_context *c, SweepMultiArgs args) {
   using ES = EpilogueShape<52, 4>;
   const size_t lds = std::max(sweep_split_slim_lds_doubles(true, 0), kExpTab + (size_t)2 * ES::SPP * ES::stride(56)) * sizeof(double);
@@ -1326,7 +1351,7 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
   // weighs for itself; GPDLA_EXPANDED_RECORDS=1 (diagnostic): the sweeps on pre-expanded records
   static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
   static const bool expanded = std::getenv("GPDLA_EXPANDED_RECORDS") != nullptr;
-  const RecordClass cls = (b->k > 20 && !legacy && !expanded) ? kRecSlim40 : kRecExpanded;
+  const RecordClass cls = expanded ? kRecExpanded : b->k <= 20 ? kRecSlim20 : !legacy ? kRecSlim40 : kRecExpanded;
   if ((rc = plan_records(c, b, record_class_doubles(cls, b->ntiles, false), true))) return rc;
   if ((rc = launch_prepare(c, b, true))) return rc;
   if ((rc = launch_build_records(c, b, 0, b->nq, false, cls))) return rc;
@@ -1389,7 +1414,8 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
         sa.sample_ll_lls = mb.sll_lls;
         sa.ll_no_dla = mb.ll_no;
         sa.pix = b->d_pix;
-        rc = b->k <= 20 ? launch_sweep_multi<14, 1, 8, 13>(c, b, sa)
+        rc = cls == kRecSlim20 ? launch_sweep_multi_slim(c, sa)
+             : b->k <= 20 ? launch_sweep_multi<14, 1, 8, 13>(c, b, sa)
              : legacy ? launch_sweep_multi<14, 4, 1, 52>(c, b, sa)
              : cls == kRecSlim40 ? launch_sweep_multi_split_slim(c, sa) : launch_sweep_multi_split(c, sa);
         if (rc) return rc;

@@ -29,14 +29,13 @@ from __future__ import annotations
 
 import argparse
 import os
-from dataclasses import replace
 
 import numpy as np
 
 from . import _lib, io
 from .api import (Batch, Context, batch_blocks, default_batch_size, dla_existence_prior,
-                  dla_existence_prior_multi, prefault, run_pipeline)
-from .distributed import (_world, gather_summaries, shard_bounds, summary_to_fields,
+                  dla_existence_prior_multi, run_pipeline)
+from .distributed import (_world, agree_on_failure, gather_summaries, shard_bounds, summary_to_fields,
                           summary_to_fields_multi)
 from .parameters import MultiParameters, Parameters
 
@@ -79,6 +78,28 @@ def ramped_blocks(n: int, batch: int, ramp: int = 8):
     return blocks, small
 
 
+#: host bytes one batch's per-sample tables may take in a multi-DLA run (they are 6.5 times the
+#: single-DLA table per quasar): the batch size is capped so that the staging buffer stays this small
+MULTI_STAGING_BYTES = 512 << 20
+
+
+def _staging(rows: int, S: int, md: int) -> dict:
+    """ONE batch's worth of host arrays for the downloads of a run (per-sample tables included),
+    page-locked where torch can provide that (a device-to-host copy into pageable memory is staged
+    through a bounce buffer by the runtime and runs at less than half the rate)."""
+    out = Batch.empty_results_multi(rows, md, S) if md else Batch.empty_results(rows, S)
+    try:
+        import torch
+        for name in ("sample_log_likelihoods_dla", "sample_log_likelihoods_lls", "base_sample_inds"):
+            if name in out and out[name].size:
+                t = torch.empty(out[name].nbytes, dtype=torch.uint8, pin_memory=True)
+                out[name] = t.numpy().view(out[name].dtype).reshape(out[name].shape)
+                out.setdefault("_pinned", []).append(t)  # keeps the allocation alive
+    except Exception:  # no pinned memory (no GPU runtime): pageable arrays work, slower
+        pass
+    return out
+
+
 def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file: str, out_dir: str,
         test_set_name: str = "dr12q", test_ind=None, prior_catalog: dict | None = None,
         multi: bool = False, params: Parameters | None = None, Z_lls: float | None = None,
@@ -88,6 +109,16 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
 
     ``prior_catalog``: ``{"z_qsos", "dla_ind"}`` of the training release (``api.prepare_prior``);
     multi-DLA runs also need ``Z_lls`` / ``Z_dla`` (set_lls_parameters.m:59-71).
+    Host memory is bounded by ONE batch: each batch's results are downloaded into a page-locked
+    staging buffer, its per-sample tables are handed to the chunk writer from there, and only the
+    per-quasar variables (a few hundred bytes per quasar) are kept for the end of the file -- the
+    reference pre-fills the whole run's tables (process_qsos.m:74-82) and saves them at the end
+    (:250), and its recombination script is known for the 150 GB that costs
+    (CDDF_analysis/sbatch_reunion.py:6-7).
+    A rank that fails does not leave the others waiting: every rank reports before the gather
+    (:func:`distributed.agree_on_failure`) and every rank raises; the failing rank removes its partial
+    chunk file, the finished chunks of the others stay (each is a complete file for its block, as
+    the chunks of the reference's independent jobs are, CDDF_analysis/sbatch_reunion.py:13-27).
     Returns ``dict(fields=<posterior variables of ALL quasars of the run>, block=(lo, hi),
     chunk=<path of this rank's chunk file or None>, selected=<catalogue indices of the run>,
     timings=<seconds: setup_s, pipeline_s, save_s, total_s>)``."""
@@ -99,108 +130,139 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
     timings = {}
     world, rank = _world()
     p = params or (MultiParameters() if multi else Parameters())
+    md = p.max_dlas if multi else 0
     if device is None:
         device = torch.cuda.current_device()
-    if prior_catalog is None:
-        raise ValueError("need prior_catalog (z_qsos, dla_ind of the training release)")
-    catalog = io.load_catalog(catalog_file)
-    z_all = np.asarray(catalog["z_qsos"], dtype=np.float64).reshape(-1)
-    sel = select_test_ind(catalog, test_ind)
-    model = io.load_learned_model(learned_file)
-    samples = io.load_dla_samples(samples_file)
-    S, k = samples["offset_samples"].size, model["M"].shape[1]
-    os.makedirs(out_dir, exist_ok=True)
-    reader = io.PreloadedReader(preloaded_file)
+    state = dict(chunk=None, writer=None)
+
+    def local_work():
+        """Everything this rank does on its own: returns (sel, z_all, bounds, table)."""
+        if prior_catalog is None:
+            raise ValueError("need prior_catalog (z_qsos, dla_ind of the training release)")
+        catalog = io.load_catalog(catalog_file)
+        z_all = np.asarray(catalog["z_qsos"], dtype=np.float64).reshape(-1)
+        sel = select_test_ind(catalog, test_ind)
+        model = io.load_learned_model(learned_file)
+        samples = io.load_dla_samples(samples_file)
+        S, k = samples["offset_samples"].size, model["M"].shape[1]
+        os.makedirs(out_dir, exist_ok=True)
+        reader = io.PreloadedReader(preloaded_file)
+        try:
+            if reader.num_quasars != z_all.size:
+                raise ValueError(f"{preloaded_file} holds {reader.num_quasars} spectra, the catalogue {z_all.size}")
+            counts = reader.pixel_counts(sel)
+            bounds = shard_bounds(counts, world)
+            lo, hi = bounds[rank]
+            nloc = hi - lo
+            z_sel = z_all[sel]
+            if multi:
+                if Z_lls is None or Z_dla is None:
+                    raise ValueError("a multi-DLA run needs Z_lls and Z_dla (set_lls_parameters.m:59-71)")
+                lp_no, lp_lls, lp_dla = dla_existence_prior_multi(prior_catalog["z_qsos"], prior_catalog["dla_ind"],
+                                                                  z_sel[lo:hi], Z_lls, Z_dla, p)
+                ncol = _lib.summary_cols_multi(md)
+            else:
+                lp_no, lp_dla = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], z_sel[lo:hi], p)
+                lp_lls = None
+                ncol = _lib.SUMMARY_COLS
+            # the rank's posterior table lives on the GPU: each batch's rows are copied into it behind
+            # its sweep (same stream), and the whole table is what the RCCL all-gather reads
+            stream = torch.cuda.Stream(device=device)
+            table = torch.empty((nloc, ncol), dtype=torch.float64, device=f"cuda:{device}")
+            if nloc:
+                per_batch = max_quasars_per_batch
+                if per_batch is None:
+                    per_batch = default_batch_size(nloc, int(counts[lo:hi].max()), k, S, pipeline_slots,
+                                                   multi_models=(md + 1) if multi else 0)
+                    if multi:  # keep the staging buffer of a batch small (see MULTI_STAGING_BYTES)
+                        per_q = S * (8 * md + 8 + 4 * max(md - 1, 0))
+                        per_batch = max(64, min(per_batch, MULTI_STAGING_BYTES // per_q))
+                blocks, grid = ramped_blocks(nloc, per_batch)
+                # per-quasar variables of the whole block (small); per-sample tables of ONE batch
+                small = (Batch.empty_results_multi(nloc, md, S, with_samples=False) if multi
+                         else Batch.empty_results(nloc, S, with_samples=False))
+                stage = _staging(max(b1 - b0 for b0, b1 in blocks), S, md)
+                ctx = Context(device, p, stream=stream)
+                # the chunk file is open from the start: the download thread transposes each batch's
+                # per-sample tables into MATLAB's order and writes them while the next batch is swept
+                state["chunk"] = io.chunk_filename(out_dir, test_set_name, lo, hi, multi)
+                writer = state["writer"] = io.ProcessedStreamWriter(state["chunk"], nloc, S, grid, md)
+                copied = [None] * len(blocks)
+
+                def inputs(i):  # runs on the upload thread: file reads overlap the sweep in flight
+                    b0, b1 = blocks[i]
+                    spectra = reader.read_csr(sel[lo + b0:lo + b1], z_all)  # flat arrays, native reader (csrc/h5cells.c)
+                    args = (spectra, lp_no[b0:b1], lp_dla[b0:b1])
+                    return args + ((lp_lls[b0:b1],) if multi else ())
+
+                def process(i, batch):
+                    b0, b1 = blocks[i]
+                    with torch.cuda.stream(stream):
+                        if multi:
+                            ctx.set_first_quasar_index(p.first_quasar_index + lo + b0)
+                            batch.process_multi()
+                        else:
+                            batch.process()
+                        table[b0:b1].copy_(batch.summary_tensor())
+                        # (the slot must not be re-filled before this copy has run: see distributed.py)
+                        copied[i] = torch.cuda.Event()
+                        copied[i].record(stream)
+
+                def download(i, batch):  # the one download thread: the staging buffer is its own
+                    b0, b1 = blocks[i]
+                    n = b1 - b0
+                    (batch.download_multi(True, stage, 0) if multi else batch.download(True, stage, 0))
+                    for name, dst in small.items():
+                        dst[b0:b1] = stage[name][:n]
+                    writer.append(b0, {k_: stage[k_][:n] for k_ in writer.streamed})
+                    copied[i].synchronize()
+
+                try:
+                    ctx.set_model(model)
+                    ctx.set_samples(samples)
+                    timings["setup_s"] = time.perf_counter() - t_start
+                    run_pipeline(ctx, len(blocks), inputs, process, download, pipeline_slots)
+                    stream.synchronize()
+                    timings["pipeline_s"] = time.perf_counter() - t_start - timings["setup_s"]
+                finally:
+                    ctx.close()
+                t_save = time.perf_counter()
+                mask = np.zeros(z_all.size, dtype=bool)
+                mask[sel[lo:hi]] = True
+                meta = dict(test_set_name=test_set_name, **(run_metadata or {}))
+                small.update(num_lines=p.num_lines, prior_z_qso_increase=p.prior_z_qso_increase, max_z_cut=p.max_z_cut)
+                if multi:
+                    small.update(k=k, min_z_cut=p.min_z_cut, num_dla_samples=S)
+                writer.finish(small, test_ind=mask, **meta)
+                state["writer"] = None
+                timings["save_s"] = time.perf_counter() - t_save
+        finally:
+            reader.close()
+        return sel, z_all, bounds, table, stream
+
+    def discard_chunk():
+        if state["writer"] is not None:
+            state["writer"].abort()
+        if state["chunk"] and os.path.exists(state["chunk"]):
+            os.remove(state["chunk"])  # a partial chunk file must not be mistaken for a finished one
+
+    error, result = None, None
     try:
-        if reader.num_quasars != z_all.size:
-            raise ValueError(f"{preloaded_file} holds {reader.num_quasars} spectra, the catalogue {z_all.size}")
-        counts = reader.pixel_counts(sel)
-        bounds = shard_bounds(counts, world)
-        lo, hi = bounds[rank]
-        nloc = hi - lo
-        z_sel = z_all[sel]
-        if multi:
-            if Z_lls is None or Z_dla is None:
-                raise ValueError("a multi-DLA run needs Z_lls and Z_dla (set_lls_parameters.m:59-71)")
-            lp_no, lp_lls, lp_dla = dla_existence_prior_multi(prior_catalog["z_qsos"], prior_catalog["dla_ind"],
-                                                              z_sel[lo:hi], Z_lls, Z_dla, p)
-            ncol = _lib.summary_cols_multi(p.max_dlas)
-        else:
-            lp_no, lp_dla = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], z_sel[lo:hi], p)
-            lp_lls = None
-            ncol = _lib.SUMMARY_COLS
-        # the rank's posterior table lives on the GPU: each batch's rows are copied into it behind
-        # its sweep (same stream), and the whole table is what the RCCL all-gather reads
-        stream = torch.cuda.Stream(device=device)
-        table = torch.empty((nloc, ncol), dtype=torch.float64, device=f"cuda:{device}")
-        local = None
-        chunk = None
-        if nloc:
-            if max_quasars_per_batch is None:
-                max_quasars_per_batch = default_batch_size(nloc, int(counts[lo:hi].max()), k, S, pipeline_slots,
-                                                           multi_models=(p.max_dlas + 1) if multi else 0)
-            blocks, grid = ramped_blocks(nloc, max_quasars_per_batch)
-            local = (Batch.empty_results_multi(nloc, p.max_dlas, S) if multi else Batch.empty_results(nloc, S))
-            ctx = Context(device, p, stream=stream)
-            # the chunk file is open from the start: the download thread transposes each batch's
-            # per-sample tables into MATLAB's order and writes them while the next batch is swept
-            chunk = io.chunk_filename(out_dir, test_set_name, lo, hi, multi)
-            writer = io.ProcessedStreamWriter(chunk, nloc, S, grid, p.max_dlas if multi else 0)
-
-            def inputs(i):  # runs on the upload thread: file reads overlap the sweep in flight
-                b0, b1 = blocks[i]
-                spectra = reader.read_csr(sel[lo + b0:lo + b1], z_all)  # flat arrays, native reader (csrc/h5cells.c)
-                args = (spectra, lp_no[b0:b1], lp_dla[b0:b1])
-                return args + ((lp_lls[b0:b1],) if multi else ())
-
-            def process(i, batch):
-                b0, b1 = blocks[i]
-                with torch.cuda.stream(stream):
-                    if multi:
-                        ctx.set_params(replace(p, first_quasar_index=p.first_quasar_index + lo + b0))
-                        batch.process_multi()
-                    else:
-                        batch.process()
-                    table[b0:b1].copy_(batch.summary_tensor())
-
-            def download(i, batch):
-                b0, b1 = blocks[i]
-                (batch.download_multi(True, local, b0) if multi else batch.download(True, local, b0))
-                writer.append(b0, {k_: local[k_][b0:b1] for k_ in writer.streamed})
-
-            try:
-                ctx.set_model(model)
-                ctx.set_samples(samples)
-                timings["setup_s"] = time.perf_counter() - t_start
-                run_pipeline(ctx, len(blocks), inputs, process, download, pipeline_slots,
-                             warm=lambda: prefault(local["sample_log_likelihoods_dla"]))
-                stream.synchronize()
-                timings["pipeline_s"] = time.perf_counter() - t_start - timings["setup_s"]
-            except BaseException:
-                writer.abort()
-                if os.path.exists(chunk):
-                    os.remove(chunk)  # a partial chunk file must not be mistaken for a finished one
-                raise
-            finally:
-                ctx.close()
-    finally:
-        reader.close()
-    t_save = time.perf_counter()
-
-    if nloc:
-        mask = np.zeros(z_all.size, dtype=bool)
-        mask[sel[lo:hi]] = True
-        meta = dict(test_set_name=test_set_name, **(run_metadata or {}))
-        local.update(num_lines=p.num_lines, prior_z_qso_increase=p.prior_z_qso_increase, max_z_cut=p.max_z_cut)
-        if multi:
-            local.update(k=k, min_z_cut=p.min_z_cut, num_dla_samples=S)
-        writer.finish(local, test_ind=mask, **meta)
-
-    timings["save_s"] = time.perf_counter() - t_save
+        result = local_work()
+    except Exception as e:
+        error = e
+    try:
+        agree_on_failure(error, what="file-to-file run")  # raises on EVERY rank if any rank failed
+    except BaseException:
+        if error is not None:  # (a finished chunk of a rank that did not fail stays: it is complete)
+            discard_chunk()
+        raise
+    sel, z_all, bounds, table, stream = result
+    timings.setdefault("save_s", 0.0)
     with torch.cuda.stream(stream):
         gathered = gather_summaries(table, [b[1] - b[0] for b in bounds])
     stream.synchronize()
-    fields = summary_to_fields_multi(gathered, p.max_dlas) if multi else summary_to_fields(gathered)
+    fields = summary_to_fields_multi(gathered, md) if multi else summary_to_fields(gathered)
     if write_summary and rank == 0:
         mask = np.zeros(z_all.size, dtype=bool)
         mask[sel] = True
@@ -208,7 +270,7 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
         io.savemat73(os.path.join(out_dir, stem + "_summary.mat"),
                      dict(test_ind=mask.reshape(-1, 1), **{k_: v for k_, v in fields.items()}))
     timings["total_s"] = time.perf_counter() - t_start
-    return dict(fields=fields, block=(lo, hi), chunk=chunk, selected=sel, timings=timings)
+    return dict(fields=fields, block=bounds[rank], chunk=state["chunk"], selected=sel, timings=timings)
 
 
 def main(argv=None):
@@ -227,6 +289,9 @@ def main(argv=None):
     ap.add_argument("--max-dlas", type=int, default=4)
     ap.add_argument("--batch", type=int, default=None, help="quasars per HBM-resident batch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--timeout-min", type=float, default=30.0,
+                    help="process-group timeout: how long a rank waits in a collective for a rank that died "
+                         "without reporting (a rank that RAISES is agreed on at once)")
     args = ap.parse_args(argv)
 
     import torch
@@ -235,8 +300,9 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         kw = dict(device_id=torch.device("cuda", local_rank)) if args.backend == "nccl" else {}
-        dist.init_process_group(args.backend, **kw)
+        dist.init_process_group(args.backend, timeout=datetime.timedelta(minutes=args.timeout_min), **kw)
     try:
         if args.prior.endswith(".npz"):
             pr = np.load(args.prior)

@@ -104,19 +104,33 @@ def run_rccl_world1(port, out_dir):
         dist.destroy_process_group()
 
 
-def run_files_rank(rank, world, port, multi, in_dir, out_dir, per_batch):
+def run_files_rank(rank, world, port, multi, in_dir, out_dir, per_batch, fail_rank=None):
     """One rank of the file-to-file run (gp_dla_detection_amd.run_dr12q.run) on cuda:0 over gloo:
     reads the synthetic file set in ``in_dir`` (synthetic.write_file_set), writes its chunk file
-    into ``out_dir`` and saves what it returned."""
+    into ``out_dir`` and saves what it returned.  ``fail_rank``: that rank's reader raises when it is
+    asked for its second batch (a damaged input file); every rank then records how the run ended."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    import time
+
     import torch
     import torch.distributed as dist
 
-    from gp_dla_detection_amd import run_dr12q
+    from gp_dla_detection_amd import io, run_dr12q
     from gp_dla_detection_amd.parameters import MultiParameters
     torch.cuda.set_device(0)
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    if fail_rank is not None and rank == fail_rank:
+        real, calls = io.PreloadedReader.read_csr, []
+
+        def read_csr(self, indices, z_qsos):
+            calls.append(len(indices))
+            if len(calls) == 2:
+                raise OSError("injected: cell 2 of preloaded_qsos.mat cannot be read")
+            return real(self, indices, z_qsos)
+        io.PreloadedReader.read_csr = read_csr
+    t0 = time.perf_counter()
     try:
         pr = np.load(os.path.join(in_dir, "prior_catalog.npz"))
         res = run_dr12q.run(os.path.join(in_dir, "preloaded_qsos.mat"), os.path.join(in_dir, "catalog.mat"),
@@ -130,6 +144,11 @@ def run_files_rank(rank, world, port, multi, in_dir, out_dir, per_batch):
         np.savez(os.path.join(out_dir, f"files_{'multi' if multi else 'single'}_w{world}_r{rank}.npz"),
                  block=np.array(res["block"]), chunk=np.array(res["chunk"] or ""), selected=res["selected"],
                  **{"f_" + k: v for k, v in res["fields"].items()})
+    except Exception as e:
+        if fail_rank is None:
+            raise
+        with open(os.path.join(out_dir, f"ended_r{rank}.txt"), "w") as f:
+            f.write(f"{type(e).__name__}\n{time.perf_counter() - t0}\n")
     finally:
         if world > 1:
             dist.destroy_process_group()

@@ -134,3 +134,50 @@ def test_run_sharded_gloo_world2(tmp_path, sizes):
     want = np.arange(nq, dtype=np.float64)[:, None] + np.arange(NCOL)[None, :] / 100
     for r in range(world):
         np.testing.assert_array_equal(np.load(tmp_path / f"s{r}.npy"), want)
+
+
+def _failing_worker(rank, world, port, out_dir):
+    """One rank's sweep raises: no rank may be left waiting in the all-gather."""
+    import datetime
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from gp_dla_detection_amd.distributed import ShardFailure
+    t0 = time.perf_counter()
+    outcome = "no exception"
+    try:
+        bounds = shard_bounds([500, 400, 600, 500], world)
+
+        def sweep_block(lo, hi):
+            if rank == 1:
+                raise ValueError("rank 1 cannot read its block")
+            return torch.zeros((hi - lo, NCOL), dtype=torch.float64), None
+
+        try:
+            run_sharded(bounds, rank, NCOL, sweep_block)
+        except ShardFailure:
+            outcome = "ShardFailure"
+        except ValueError as e:
+            outcome = f"ValueError: {e}"
+        with open(os.path.join(out_dir, f"f{rank}.txt"), "w") as f:
+            f.write(f"{outcome}\n{time.perf_counter() - t0}\n")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_ends_the_sharded_run_on_every_rank(tmp_path):
+    """distributed.agree_on_failure: the rank that raised re-raises its own exception, the other rank
+    raises ShardFailure at once -- nobody waits for the collective timeout (120 s here)."""
+    world = 2
+    mp.spawn(_failing_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [open(tmp_path / f"f{r}.txt").read().split("\n") for r in range(world)]
+    assert got[0][0] == "ShardFailure"
+    assert got[1][0] == "ValueError: rank 1 cannot read its block"
+    assert all(float(g[1]) < 30.0 for g in got)
+
+
+def test_agree_on_failure_without_a_process_group():
+    from gp_dla_detection_amd.distributed import agree_on_failure
+    agree_on_failure(None)
+    with pytest.raises(KeyError):
+        agree_on_failure(KeyError("x"))

@@ -1,6 +1,6 @@
 """The slim step records (vech(m m') formed inside the sweep) against the pre-expanded records they
-replace: k_sweep_slim vs k_sweep (k <= 20), k_sweep_split_slim vs k_sweep_split and
-k_sweep_multi_split (20 < k <= 40, single- and multi-DLA).  Same products, same MFMA sequence per
+replace: k_sweep_slim vs k_sweep and k_sweep_multi_slim vs k_sweep_multi (k <= 20),
+k_sweep_split_slim vs k_sweep_split and k_sweep_multi_split (20 < k <= 40).  Same products, same MFMA sequence per
 column, same epilogue: every output must be bit-identical.  The expanded path is selected by the
 diagnostic switch GPDLA_EXPANDED_RECORDS=1, which the library reads once per process, so it runs in
 a clean child (hot loops: process_qsos.m:185-199, process_qsos_multiple_dlas_meanflux.m:340-381)."""
@@ -29,7 +29,7 @@ def expanded(kind, k, num_lines, tmp_path, extra_env=None):
 
 
 @pytest.mark.parametrize("kind,k,num_lines", [("single", 20, 3), ("single", 40, 3), ("single", 33, 3),
-                                              ("single", 27, 5), ("multi", 40, 3), ("multi", 23, 3)])
+                                              ("single", 27, 5), ("multi", 40, 3), ("multi", 23, 3), ("multi", 20, 3), ("multi", 17, 3)])
 def test_slim_records_reproduce_the_expanded_records_bit_for_bit(kind, k, num_lines, tmp_path):
     want = expanded(kind, k, num_lines, tmp_path)
     got = rcw.run_case(kind, k, num_lines)

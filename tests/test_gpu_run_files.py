@@ -104,6 +104,33 @@ def test_file_to_file_run_equals_the_unsharded_run(fileset, tmp_path, world, mul
     np.testing.assert_array_equal(summary["p_dlas"].reshape(-1), ref["p_dlas"])
 
 
+def test_a_failing_rank_ends_the_file_run_on_every_rank(fileset, tmp_path):
+    """World 2 on the GPU, rank 1's input reader raises at its second batch: rank 1 re-raises its
+    error and removes its partial chunk, rank 0 -- whose chunk is complete and stays -- raises
+    ShardFailure instead of waiting in the all-gather; no summary file is written."""
+    in_dir = os.path.dirname(fileset["paths"]["catalog"])
+    ctx = mp.get_context("forkserver")
+    port = free_port()
+    procs = [ctx.Process(target=sharded_worker.run_files_rank, args=(r, 2, port, False, in_dir, str(tmp_path), 2, 1))
+             for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(600)
+    for pr in procs:
+        if pr.is_alive():
+            pr.kill()
+            pr.join()
+    assert [pr.exitcode for pr in procs] == [0, 0]  # (the worker records the exception and exits)
+    ended = [open(tmp_path / f"ended_r{r}.txt").read().split("\n") for r in range(2)]
+    assert ended[0][0] == "ShardFailure" and ended[1][0] == "OSError"
+    assert all(float(e[1]) < 120.0 for e in ended)
+    chunks = sorted(glob.glob(str(tmp_path / "processed_qsos_synth_[0-9]*.mat")))
+    assert len(chunks) == 1 and "_000000-" in chunks[0]
+    io.load_processed_qsos(chunks[0])  # complete and readable
+    assert not glob.glob(str(tmp_path / "*summary.mat"))
+
+
 def test_committed_consumer_chunks_are_reproduced(tmp_path):
     """The chunk files under tests/golden/consumer/ -- the ones the reference's mat_combine, QSOLoader
     and DLACatalogue were run on (tests/test_consumers.py) -- are what a world-2 run on this GPU

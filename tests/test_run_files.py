@@ -96,7 +96,8 @@ def test_chunks_recombine_to_the_whole_run(tmp_path, md):
 def test_batch_size_defaults():
     assert 0.33e6 < record_bytes_per_quasar(1500, 20) < 0.4e6          # slim records: 896 B per K-step
     assert 2.8e6 < record_bytes_per_quasar(1500, 20, slim=False) < 3.0e6
-    assert 11e6 < record_bytes_per_quasar(1500, 40) < 11.3e6
+    assert 0.57e6 < record_bytes_per_quasar(1500, 40) < 0.6e6          # k <= 40 slim records: 1536 B per K-step
+    assert 11e6 < record_bytes_per_quasar(1500, 40, slim=False) < 11.3e6
     assert default_batch_size(2048, 1500, 20, 10000, 3) == 256
     assert default_batch_size(100, 1500, 20, 10000, 3) in (100, 128)
     assert default_batch_size(10 ** 6, 1500, 20, 10000, 3) == 4096
