@@ -30,7 +30,8 @@
 //     The multi-DLA form gathers profile values in place of stage R.
 //
 // Results are bit-identical to the pre-expanded kernels': the same products, the same MFMA sequence
-// per column, the same epilogue.
+// per column, the same epilogue.  (S40_EXP_*: ablation switches of diagnostic builds, tools/ab_build.sh;
+// their results are wrong by construction.)
 #pragma once
 #include <type_traits>
 
@@ -395,18 +396,35 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
 #pragma unroll
           for (int cc = 0; cc < NTW; ++cc) {
             opa[cc] = lds_at(pa[cc], off);
+#ifndef S40_EXP_NOMUL
             opb[cc] = lds_at(pb[cc], off);
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);  // all 18 reads requested before the first product waits
 #pragma unroll
-          for (int cc = 0; cc < NTW; ++cc) bop[cc] = opa[cc] * opb[cc];
+          for (int cc = 0; cc < NTW; ++cc) {
+#ifdef S40_EXP_NOMUL
+            bop[cc] = opa[cc];
+#else
+            bop[cc] = opa[cc] * opb[cc];
+#endif
+          }
+#ifdef S40_EXP_NOMFMA
+#pragma unroll
+          for (int cc = 0; cc < NTW; ++cc) {
+            asm volatile("" ::"v"(bop[cc]));
+            if (cc < 1) acc0[cc][0] += (cc < 3 ? w0 : t0) * bop[cc] + w1 * t1;
+          }
+#else
 #pragma unroll
           for (int cc = 0; cc < NTW; ++cc) {
             acc0[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < 3 ? w0 : t0, bop[cc], acc0[cc], 0, 0, 0);
             acc1[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < 3 ? w1 : t1, bop[cc], acc1[cc], 0, 0, 0);
           }
+#endif
         }
       }
+#ifndef S40_EXP_NOWR
       double w1, u1;
       if constexpr (kMulti) {
         weigh(t_w, px_w, absorb_gathered(g_cur[h]), &w1, &u1);
@@ -418,9 +436,14 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
       *wu_at(PAR ^ 1, group, 0, 4 * h + role) = w1;
       *wu_at(PAR ^ 1, group, 1, 4 * h + role) = u1;
       if constexpr (!kMulti) my_ring[(4 * t_r + jj) & 127] = raw_of(lam_r);
+#else
+      asm volatile("" ::"v"(px_w.y), "v"(lam_r));
+#endif
     }
     glds_wait();
+#ifndef S40_EXP_NOBAR
     __syncthreads();
+#endif
   };
   for (int it = 0; it < niter; it += 2) {
     iteration(std::integral_constant<int, 0>{}, it);
@@ -472,8 +495,12 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
     const int rho = 2 * role + (lane >> 5);
     const int sigma = (rho >> 1) + 4 * (2 * p + (rho & 1));  // Mat<double>::sample_of(jj, reg)
     const double q_s = __shfl(quad_sum, sigma), ld_s = __shfl(logd_sum, sigma);
+#ifdef S40_EXP_NOEPI
+    const double ll = q_s + ld_s + Eg[(size_t)(group * ES::SPP + rho) * ncols + (lane & 31)];
+#else
     const double ll = factor_lds<2, 32>(Eg + (size_t)(group * ES::SPP + rho) * ncols, lane & 31, a.k, voff, q_s, ld_s,
                                         m.n_kept);
+#endif
     const int64_t slot_s = slot0 + sigma;
     if constexpr (kMulti) {
       const bool ok_s = __shfl(chain_ok, sigma) != 0;

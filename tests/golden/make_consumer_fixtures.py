@@ -153,6 +153,17 @@ def main():
                 cat = q.generate_json_catalogue(outfile=os.path.join(OUT, "expected_predictions_multi_DLAs.json"))
                 sub = q.generate_sub_dla_catalogue(outfile=os.path.join(OUT, "expected_predictions_sub_DLA_candidates.json"))
                 report["json_records"] = [len(cat), len(sub)]
+                # The reference restates the (2 + max_dlas)-way softmax of multi :482-495 in Python:
+                # QSOLoader.reevaluate_model_posteriors (qso_loader.py:260-283) recomputes model_posteriors
+                # from the file's log_posteriors_*.  It only does so when some row of the posteriors it
+                # holds sums to more than 1.2, so that condition is made true first (LAST use of q: the
+                # call replaces q.model_posteriors).  What it returns anchors k_multi_posteriors.
+                q.model_posteriors = np.asarray(q.model_posteriors) * 2.0
+                q.reevaluate_model_posteriors()
+                np.savez_compressed(os.path.join(OUT, "expected_reevaluated_posteriors_multi.npz"),
+                                    model_posteriors=np.asarray(q.model_posteriors),
+                                    log_posteriors=np.asarray(q.log_posteriors))
+                report["reevaluate_model_posteriors"] = "ok: %d quasars x %d models" % np.asarray(q.model_posteriors).shape
             c = calc_cddf.DLACatalogue(processed_file=combined, sample_file=f"{d}/dla_samples.mat",
                                        raw_file=f"{d}/preloaded_qsos.mat", snrs_file=f"{d}/snrs_qsos.mat",
                                        snr=-2, second=1 if multi else False, sub_dla=multi, occams_razor=10000)

@@ -15,7 +15,8 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 def _env():
     env = {k: v for k, v in os.environ.items()
-           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "HSA_ENABLE_IPC_MODE_LEGACY")}
     return env
 
 
@@ -28,6 +29,7 @@ def test_self_launch_starts_n_ranks_and_prints_one_line(n):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == n and out["rank_sum"] == n * (n - 1) / 2 == out["local_rank_sum"]
+    assert out["hsa_enable_ipc_mode_legacy"] == "0"  # the same RCCL environment in both launch forms
 
 
 def test_torchrun_form_still_works():
@@ -37,6 +39,7 @@ def test_torchrun_form_still_works():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    assert json.loads(lines[0])["hsa_enable_ipc_mode_legacy"] == "0"
 
 
 def test_a_failing_rank_ends_the_launch():

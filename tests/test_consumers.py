@@ -190,6 +190,24 @@ def test_committed_chunks_are_what_the_package_reads(inputs):
     assert lo == 32
 
 
+def test_model_posteriors_equal_the_references_reevaluation():
+    """A reference-PRODUCED anchor of the posterior softmax (multi :482-495): the reference restates
+    it as QSOLoader.reevaluate_model_posteriors (qso_loader.py:260-283), which was run on the
+    committed multi-DLA chunk files (tests/golden/make_consumer_fixtures.py).  The model_posteriors
+    in those files were computed on the GPU by k_multi_posteriors from the same log posteriors."""
+    ref = np.load(os.path.join(CONS, "expected_reevaluated_posteriors_multi.npz"))
+    parts = [io.load_processed_qsos(p) for p in chunks(True)]
+    got = np.concatenate([p["model_posteriors"] for p in parts], axis=0)
+    lpost = np.concatenate([np.column_stack([p["log_posteriors_no_dla"], p["log_posteriors_lls"],
+                                             p["log_posteriors_dla"]]) for p in parts], axis=0)
+    np.testing.assert_array_equal(lpost, ref["log_posteriors"])  # the reference read what the files hold
+    assert got.shape == ref["model_posteriors"].shape == (32, 5)
+    np.testing.assert_allclose(got, ref["model_posteriors"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate([p["p_dlas"] for p in parts]),
+                               1 - ref["model_posteriors"][:, 0] - ref["model_posteriors"][:, 1], rtol=0, atol=1e-12)
+    assert (ref["model_posteriors"].max(axis=1) > 0.5).all() and len({int(i) for i in ref["model_posteriors"].argmax(axis=1)}) >= 2
+
+
 # ---------------------------------------------------------------------------------------------
 # libhdf5 cross-read of the writer (h5dump / h5ls from the conda environment of the build image)
 # ---------------------------------------------------------------------------------------------

@@ -94,6 +94,47 @@ def test_gpu_resampling_then_oracle(oracle):
         assert abs(out["p_dlas"][i] - (1 - mp[0] - mp[1])) < 1e-9
 
 
+def test_gpu_drawn_early_exit(oracle):
+    """multi :460-464 reached on the GPU itself, with indices the GPU drew: a min_z_separation wider
+    than the whole search range masks every sample of the two-DLA model (:386-392), so its evidence
+    is NaN (nanmax / nanmean of an all-NaN column, :400-409) and the loop ends there -- models 3 and
+    4 are never evaluated (their tables keep the NaN pre-fill of :110-131), the rows of
+    base_sample_inds that would have fed them stay zero (:116), the MAP of the all-NaN model is
+    index 1 with its drawn partner (MATLAB's nanmax, :439-445), and every posterior of the quasar is
+    NaN because MATLAB's max skips NaN and its sum does not (:482-491).  The oracle, handed the
+    returned indices, takes the same exit."""
+    p = MultiParameters(max_dlas=4, min_z_separation=10.0)
+    model = synthetic.make_model(20)
+    S = 128
+    samples = synthetic.make_samples(S)
+    spectra = [synthetic.make_spectrum(90 + i, n, model, mask_fraction=0.03 if i else 0.0)
+               for i, n in enumerate([300, 217])]
+    lp = priors(spectra, p)
+    out = gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=p)
+    bsi = out["base_sample_inds"]
+    assert bsi.shape == (2, 3, S)
+    assert (bsi[:, 0] >= 1).all() and (bsi[:, 0] <= S).all()   # drawn from the one-DLA model's weights
+    assert (bsi[:, 1:] == 0).all()                             # never drawn: the loop had ended
+    sll = out["sample_log_likelihoods_dla"]
+    assert np.isfinite(sll[:, 0]).all() and np.isnan(sll[:, 1:]).all()
+    assert np.isfinite(out["log_likelihoods_dla"][:, 0]).all() and np.isnan(out["log_likelihoods_dla"][:, 1:]).all()
+    assert np.isfinite(out["log_posteriors_dla"][:, 0]).all() and np.isnan(out["log_posteriors_dla"][:, 1:]).all()
+    assert np.isfinite(out["log_likelihoods_lls"]).all() and np.isfinite(out["log_posteriors_no_dla"]).all()
+    for i in range(2):
+        np.testing.assert_array_equal(out["MAP_inds"][i, 1], [1.0, float(bsi[i, 0, 0]), np.nan, np.nan])
+        assert np.isfinite(out["MAP_z_dlas"][i, 1, :2]).all() and np.isnan(out["MAP_z_dlas"][i, 1, 2:]).all()
+        assert np.isnan(out["MAP_inds"][i, 2:]).all() and np.isnan(out["MAP_log_nhis"][i, 2:]).all()
+    for key in ("model_posteriors", "p_no_dlas", "p_lls", "p_dlas"):
+        assert np.isnan(out[key]).all(), key
+    for i, sp in enumerate(spectra):
+        compare(out, i, oracle_multi(oracle, model, samples, sp, bsi[i], p), p)
+    # the same quasars with the reference's separation: nothing exits, every model is evaluated
+    full = gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=MultiParameters(max_dlas=4))
+    np.testing.assert_array_equal(full["sample_log_likelihoods_dla"][:, 0], sll[:, 0])
+    np.testing.assert_array_equal(full["base_sample_inds"][:, 0], bsi[:, 0])
+    assert np.isfinite(full["log_likelihoods_dla"]).all() and (full["base_sample_inds"] >= 1).all()
+
+
 def test_rank_40_multi_dla(oracle):
     """The multi-DLA sweep on the k <= 40 kernel (tile split over four waves), every model order."""
     p = MultiParameters(max_dlas=3)

@@ -139,6 +139,7 @@ def test_committed_consumer_chunks_are_reproduced(tmp_path):
     cons = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consumer")
     fs = synthetic.write_file_set(str(tmp_path / "in"), num_quasars=40, num_samples=24, empty_quasar=None)
     in_dir = os.path.dirname(fs["paths"]["catalog"])
+    reevaluated = np.load(os.path.join(cons, "expected_reevaluated_posteriors_multi.npz"))["model_posteriors"]
     for multi in (False, True):
         out = tmp_path / ("multi" if multi else "single")
         out.mkdir()
@@ -147,6 +148,9 @@ def test_committed_consumer_chunks_are_reproduced(tmp_path):
         new = sorted(glob.glob(str(out / (stem + "[0-9]*.mat"))))
         old = sorted(glob.glob(os.path.join(cons, stem + "[0-9]*.mat")))
         assert [os.path.basename(p) for p in new] == [os.path.basename(p) for p in old] and len(old) == 2
+        if multi:  # k_multi_posteriors of THIS run against the reference's own softmax (qso_loader.py:260-283)
+            now = np.concatenate([io.load_processed_qsos(p)["model_posteriors"] for p in new], axis=0)
+            np.testing.assert_allclose(now, reevaluated, rtol=0, atol=1e-8)
         for a, b in zip(new, old):
             pa, pb = io.load_processed_qsos(a), io.load_processed_qsos(b)
             assert sorted(pa) == sorted(pb)
