@@ -30,6 +30,7 @@ typedef struct {
   int rank;
   uint64_t dims[MAX_RANK];
   int elem_size;
+  int type_class;          /* 0 fixed-point (integer), 1 floating-point */
   int layout;              /* 0 compact, 1 contiguous, 2 chunked */
   uint64_t addr;           /* contiguous: data; chunked: B-tree */
   uint64_t size;           /* contiguous / compact: bytes */
@@ -71,6 +72,7 @@ static int take_message(cell_info *ci, int type, const uint8_t *d, size_t n, uin
     if (n < 8) return -1;
     int cls = d[0] & 0x0F;
     if ((cls != 0 && cls != 1) || (d[1] & 1)) return -1;
+    ci->type_class = cls;
     ci->elem_size = (int)u32(d + 4);
     *seen |= 2;
   } else if (type == 0x0008 && n >= 8 && (d[0] == 1 || d[0] == 2)) { /* data layout, versions 1 and 2 (HDF5 1.6) */
@@ -176,6 +178,12 @@ static int parse_cell(fd_t fd, uint64_t base, uint64_t addr, cell_info *ci) {
         return -1;
       }
       const uint8_t *d = buf + pos + 8;
+      /* message flags, bit 1: the message is SHARED -- its body is a pointer to the real message (a
+       * committed datatype, say), not the message.  Not this reader's subset: the Python reader's. */
+      if ((buf[pos + 4] & 2) && (type == 0x0001 || type == 0x0003 || type == 0x0008 || type == 0x000B)) {
+        free(buf);
+        return -1;
+      }
       if (type == 0x0010) { /* continuation */
         if (msize < 16 || nblocks == 8) {
           free(buf);
@@ -256,12 +264,15 @@ static int decode_chunk(const cell_info *ci, uint32_t mask, uint8_t *raw, size_t
 }
 
 /* Walks the chunk B-tree; copies every chunk's part of the (one-axis) vector into out. */
-static int read_chunks(fd_t fd, uint64_t base, const cell_info *ci, uint64_t node, int axis, uint8_t *out, int depth) {
+/* expect_level: the level this node must have (its parent's minus one), -1 for the root: a child that
+ * does not sit exactly one level below its parent is a damaged (possibly cyclic) tree. */
+static int read_chunks(fd_t fd, uint64_t base, const cell_info *ci, uint64_t node, int axis, uint8_t *out,
+                       int expect_level) {
   if (node == UNDEF_ADDR) return 0;
-  if (depth > 8) return -1;
   uint8_t head[24];
   if (read_at(fd, base + node, head, 24) || memcmp(head, "TREE", 4) || head[4] != 1) return -1;
   int level = head[5], used = u16(head + 6), nd = ci->rank;
+  if (expect_level < 0 ? level > 8 : level != expect_level) return -1;
   size_t ksize = 8 + 8 * (size_t)(nd + 1);
   size_t blen = (size_t)used * (ksize + 8) + ksize;
   uint8_t *body = (uint8_t *)malloc(blen);
@@ -277,7 +288,7 @@ static int read_chunks(fd_t fd, uint64_t base, const cell_info *ci, uint64_t nod
     uint32_t csize = u32(k), cmask = u32(k + 4);
     uint64_t child = u64(k + ksize);
     if (level > 0) {
-      rc = read_chunks(fd, base, ci, child, axis, out, depth + 1);
+      rc = read_chunks(fd, base, ci, child, axis, out, level - 1);
       continue;
     }
     uint64_t off = 0;
@@ -326,7 +337,7 @@ static int read_cell(fd_t fd, uint64_t base, const cell_info *ci, uint8_t *out) 
     if (i != axis && ci->cdims[i] != 1) return -1;
   if (!ci->cdims[axis]) return -1;
   memset(out, 0, bytes);
-  return read_chunks(fd, base, ci, ci->addr, axis, out, 0);
+  return read_chunks(fd, base, ci, ci->addr, axis, out, -1);
 }
 
 /* Element counts and element sizes of n cells (object-header addresses relative to `base`, the
@@ -354,11 +365,12 @@ int gpdla_h5cells_sizes(const uint8_t *file, uint64_t file_len, uint64_t base, c
 }
 
 /* Reads cell i into out + byte_offsets[i]; it must hold counts[i] elements of elem_size bytes (as
- * gpdla_h5cells_sizes reported for the SAME or a sibling cell array).  Returns the number of cells
+ * gpdla_h5cells_sizes reported for the SAME or a sibling cell array) of the class asked for
+ * (want_float: IEEE floating point, else fixed point).  Returns the number of cells
  * that could not be read as asked (their bytes are left untouched); status[i] = 0 / -1 per cell. */
 int64_t gpdla_h5cells_read(const uint8_t *file, uint64_t file_len, uint64_t base, const uint64_t *addrs, int64_t n,
-                           int32_t elem_size, void *out, const int64_t *byte_offsets, const int64_t *counts,
-                           int8_t *status, int nthreads) {
+                           int32_t elem_size, int32_t want_float, void *out, const int64_t *byte_offsets,
+                           const int64_t *counts, int8_t *status, int nthreads) {
   if (!file || !addrs || !out || !byte_offsets || !counts || !status || n < 0) return -1;
   const h5file hf = {file, file_len};
   fd_t fd = &hf;
@@ -369,7 +381,11 @@ int64_t gpdla_h5cells_read(const uint8_t *file, uint64_t file_len, uint64_t base
   for (int64_t i = 0; i < n; ++i) {
     cell_info ci;
     int rc = parse_cell(fd, base, addrs[i], &ci);
-    if (!rc && ((int64_t)cell_count(&ci) != counts[i] || ci.elem_size != elem_size)) rc = -1;
+    /* bytes are copied, never converted: the stored type must BE the array's type (an int64 cell
+     * must not land bit for bit in a float64 array -- the Python reader converts such a cell) */
+    if (!rc && ((int64_t)cell_count(&ci) != counts[i] || ci.elem_size != elem_size ||
+                ci.type_class != (want_float ? 1 : 0)))
+      rc = -1;
     if (!rc) rc = read_cell(fd, base, &ci, (uint8_t *)out + byte_offsets[i]);
     status[i] = rc ? -1 : 0;
     failed += rc ? 1 : 0;

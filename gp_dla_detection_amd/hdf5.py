@@ -553,8 +553,10 @@ class Dataset(_Node):
                 out.append((offs, csize, cmask, child))
 
     def read(self, memmap: bool = False) -> np.ndarray:
-        """The whole dataset, in HDF5 dimension order.  ``memmap=True`` returns a read-only view of
-        the file for contiguous data (no copy: use it for the 13 GB sample table)."""
+        """The whole dataset, in HDF5 dimension order, as a writable array.  ``memmap=True`` returns a
+        READ-ONLY view where that saves a copy: of the file for contiguous data, of the decompressed
+        bytes for a single-chunk dataset; chunked data are still materialised (use :meth:`read_slab`
+        to stream a large chunked table)."""
         kind, where, cdims = self._layout_info()
         shape, dt = self.shape, self.dtype
         count = self.size
@@ -571,13 +573,39 @@ class Dataset(_Node):
         if len(chunks) == 1 and tuple(cdims) == tuple(shape) and not any(chunks[0][0]):
             # one chunk holding the whole dataset (every cell of a preloaded_qsos.mat): no staging copy
             raw = self._decode_chunk(self.file._bytes(chunks[0][3], chunks[0][1]), chunks[0][2])
-            return np.frombuffer(raw, dtype=dt, count=count).reshape(shape)
+            a = np.frombuffer(raw, dtype=dt, count=count).reshape(shape)
+            return a if memmap else a.copy()  # (a copy: every path but memmap=True returns a writable array)
         out = np.zeros(shape, dtype=dt)
         for offs, csize, cmask, caddr in chunks:
             raw = self._decode_chunk(self.file._bytes(caddr, csize), cmask)
             block = np.frombuffer(raw, dtype=dt, count=int(np.prod(cdims))).reshape(cdims)
             sel = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, shape))
             out[sel] = block[tuple(slice(0, s.stop - s.start) for s in sel)]
+        return out
+
+    def read_slab(self, lo: int, hi: int) -> np.ndarray:
+        """Rows ``lo .. hi`` of the first (slowest) HDF5 dimension, touching only the data they need:
+        a view of the memory map for contiguous data, the overlapping chunks for chunked data (the
+        chunk index is walked once per dataset).  What a streamed copy of a table too large for
+        memory is built from."""
+        kind, where, cdims = self._layout_info()
+        shape, dt = self.shape, self.dtype
+        lo, hi = max(0, int(lo)), min(int(hi), shape[0] if shape else 0)
+        if kind != "chunked":
+            return self.read(memmap=True)[lo:hi]
+        if not hasattr(self, "_chunk_index"):
+            self._chunk_index = []
+            self._chunks(where, len(shape), self._chunk_index)
+        out = np.zeros((max(hi - lo, 0),) + tuple(shape[1:]), dtype=dt)
+        for offs, csize, cmask, caddr in self._chunk_index:
+            if offs[0] >= hi or offs[0] + cdims[0] <= lo:
+                continue
+            raw = self._decode_chunk(self.file._bytes(caddr, csize), cmask)
+            block = np.frombuffer(raw, dtype=dt, count=int(np.prod(cdims))).reshape(cdims)
+            a0, a1 = max(offs[0], lo), min(offs[0] + cdims[0], hi, shape[0])
+            rest = tuple(slice(o, min(o + c, s_)) for o, c, s_ in zip(offs[1:], cdims[1:], shape[1:]))
+            out[(slice(a0 - lo, a1 - lo),) + rest] = block[(slice(a0 - offs[0], a1 - offs[0]),)
+                                                           + tuple(slice(0, r.stop - r.start) for r in rest)]
         return out
 
     def __getitem__(self, key):

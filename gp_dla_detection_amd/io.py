@@ -314,7 +314,7 @@ def _load_h5cells():
                                                 C.c_void_p, C.c_int]
             lib.gpdla_h5cells_read.restype = C.c_int64
             lib.gpdla_h5cells_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.c_int32,
-                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+                                               C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             _h5cells = lib
         except Exception:  # (a missing compiler must not stop a run: the Python reader is complete)
             _h5cells = False
@@ -400,8 +400,8 @@ class PreloadedReader:
                 addrs = np.ascontiguousarray(self._refs[key][idx], dtype=np.uint64)
                 byte_off = np.ascontiguousarray(offsets[:-1] * flat.itemsize)
                 lib.gpdla_h5cells_read(self._map[0], self._map[1], self._f.userblock_size, addrs.ctypes.data, idx.size, flat.itemsize,
-                                       flat.ctypes.data, byte_off.ctypes.data, counts.ctypes.data, status.ctypes.data,
-                                       self.threads)
+                                       int(flat.dtype.kind == "f"), flat.ctypes.data, byte_off.ctypes.data,
+                                       counts.ctypes.data, status.ctypes.data, self.threads)
             for j in np.flatnonzero(status):  # the Python reader, for whatever the native one left
                 v = self._vec(key, idx[j], dt)
                 if v.size != counts[j]:
@@ -676,9 +676,10 @@ def chunk_filename(directory: str, test_set_name: str, lo: int, hi: int, multi: 
 def combine_processed_chunks(paths, out_path: str, test_ind=None) -> None:
     """What ``mat_combine`` (CDDF_analysis/sbatch_reunion.py:13-63) does -- every variable whose
     quasar axis has the first chunk's length is concatenated along that axis, everything else is
-    taken from the first chunk -- written as a MATLAB ``-v7.3`` file and streamed, so that the
-    13 GB sample table of a DR12Q run is never held in memory (the reference's script peaks at
-    ~150 GB, sbatch_reunion.py:6-7).  ``test_ind``: the combined run's selection; by default the
+    taken from the first chunk -- written as a MATLAB ``-v7.3`` file and streamed in slabs of at
+    most 256 MB (``Dataset.read_slab``: memory-mapped for contiguous sources, chunk by chunk for the
+    chunked tables the streamed writer produces), so that the 13 GB sample table of a DR12Q run is
+    never held in memory (the reference's script peaks at ~150 GB, sbatch_reunion.py:6-7).  ``test_ind``: the combined run's selection; by default the
     OR of the chunks' own masks (``mat_combine`` keeps the first chunk's, which then selects only
     that chunk's quasars)."""
     paths = list(paths)
@@ -713,12 +714,15 @@ def combine_processed_chunks(paths, out_path: str, test_ind=None) -> None:
                 if len(shape) == 1:
                     w.create_dataset(name, np.concatenate([f[name].read() for f in files]), attrs=attrs)
                     continue
-                maps = [f[name].read(memmap=True) for f in files]
+                # slab by slab along the slowest dimension: contiguous sources are memory-mapped,
+                # chunked ones (what ProcessedStreamWriter writes) are read chunk row by chunk row
+                sources = [f[name] for f in files]
                 row_bytes = int(np.prod(shape[1:])) * ds.dtype.itemsize
                 step = max(1, (256 << 20) // max(row_bytes, 1))
                 w.create_dataset_streamed(
                     name, shape, ds.dtype,
-                    (np.concatenate([m[i:i + step] for m in maps], axis=-1) for i in range(0, shape[0], step)),
+                    (np.concatenate([d.read_slab(i, i + step) for d in sources], axis=-1)
+                     for i in range(0, shape[0], step)),
                     attrs=attrs)
         finally:
             w.close()

@@ -279,6 +279,10 @@ def test_random_round_trips_hypothesis(tmp_path_factory):
             d = f["a"]
             assert d.shape == arr.shape and d.dtype == arr.dtype
             np.testing.assert_array_equal(d.read(), arr)
+            assert d.read().flags.writeable  # every layout: a caller may modify what it loaded
+            lo = data.draw(st.integers(0, shape[0]))
+            hi = data.draw(st.integers(lo, shape[0] + 2))
+            np.testing.assert_array_equal(d.read_slab(lo, hi), arr[lo:hi])  # streamed recombination reads these
             assert d.attrs["note"] == "x" and d.attrs["n"] == 7
             assert f.eof == os.path.getsize(p)
 
@@ -300,8 +304,12 @@ def test_native_cell_reader_on_a_file_written_by_matlab():
         assert counts[0] == 9 and sizes[0] == 8
         out, status = np.empty(9), np.full(1, -1, np.int8)
         off = np.zeros(1, np.int64)
-        failed = lib.gpdla_h5cells_read(view.ctypes.data, view.size, f.userblock_size, addrs.ctypes.data, 1, 8,
+        failed = lib.gpdla_h5cells_read(view.ctypes.data, view.size, f.userblock_size, addrs.ctypes.data, 1, 8, 1,
                                         out.ctypes.data, off.ctypes.data, counts.ctypes.data, status.ctypes.data, 1)
         assert failed == 0 and status[0] == 0
         np.testing.assert_array_equal(out, f["testdouble"].read().ravel())
+        # asked for as 8-byte INTEGERS the same cell is refused (bytes are copied, never converted)
+        failed = lib.gpdla_h5cells_read(view.ctypes.data, view.size, f.userblock_size, addrs.ctypes.data, 1, 8, 0,
+                                        out.ctypes.data, off.ctypes.data, counts.ctypes.data, status.ctypes.data, 1)
+        assert failed == 1 and status[0] == -1
         del view

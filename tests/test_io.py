@@ -221,6 +221,25 @@ def test_native_cell_reader_equals_the_python_reader(tmp_path, monkeypatch):
             monkeypatch.setattr(io, "_h5cells", None)
 
 
+def test_integer_cells_are_converted_not_reinterpreted(tmp_path):
+    """A cell stored as 8-byte integers (a spectrum someone saved as int64) must reach the float64
+    arrays CONVERTED: the native reader copies bytes and therefore refuses a cell whose stored class
+    is not the array's (csrc/h5cells.c), the Python reader takes it and converts."""
+    rng = np.random.default_rng(3)
+    lens = [40, 600, 25]
+    cells = {k: [rng.standard_normal((m, 1)) for m in lens] for k in ("all_wavelengths", "all_noise_variance")}
+    cells["all_flux"] = [rng.standard_normal((lens[0], 1)), rng.integers(-5, 5, (lens[1], 1)).astype(np.int64),
+                         rng.standard_normal((lens[2], 1))]
+    cells["all_pixel_mask"] = [rng.uniform(size=(m, 1)) < 0.2 for m in lens]
+    p = str(tmp_path / "ints.mat")
+    io.savemat73(p, cells)
+    with io.PreloadedReader(p) as r:
+        got = r.read_csr(np.arange(3), np.array([2.5, 3.0, 3.5]))
+    flux = np.concatenate([c.reshape(-1).astype(np.float64) for c in cells["all_flux"]])
+    assert got["flux"].dtype == np.float64
+    np.testing.assert_array_equal(got["flux"], flux)
+
+
 def test_streamed_processed_writer_refuses_misuse(tmp_path):
     """io.ProcessedStreamWriter: batches must sit on the chunk grid (any multiple of it, the last one
     ragged), may arrive in any order, and finish() refuses an incomplete run."""
