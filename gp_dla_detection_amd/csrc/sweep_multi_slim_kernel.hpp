@@ -14,6 +14,7 @@
 #pragma once
 #include "multi_kernels.hpp"
 #include "sweep_slim_kernel.hpp"
+#include "sweep_split_slim_kernel.hpp"  // vmcnt_imm
 
 namespace gpdla {
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
   const double *a8 = s < 8 ? row : bc + (slim_pair_i(8, s) - 16);
   const double *b8 = s < 8 ? row + 8 : bc + (slim_pair_j(8, s) - 16);
   struct Operands {
-    double mc, o[2], p8;
+    double mc, o[4], p8;
   };
   auto expand_load = [&](int t0, int t1, Operands &x) {
     x.mc = row[0];
@@ -156,8 +157,11 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
 #pragma unroll
     for (int tt = 0; tt < CH; ++tt) {
       const int rn = c * CH + tt;
-      constexpr int kXS = 7;  // K-steps that carry expansion work (k_sweep_slim)
-      constexpr int kT0[7] = {0, 2, 4, 6, 8, 10, 12}, kT1[7] = {2, 4, 6, 8, 10, 12, 13};
+      // K-steps 0..3 carry the expansion of this wave's K-step of the next chunk (4 + 3 + 3 + 3 tiles); the
+      // landing zone is refilled at the top of K-step 4, so that the only memory operations younger than
+      // it at the chunk's end are the profile gathers of K-steps 4..7 (see the wait below)
+      constexpr int kXS = 4;
+      constexpr int kT0[4] = {0, 4, 7, 10}, kT1[4] = {4, 7, 10, 13};
       if (tt == kXS && c + 2 < nchunks) issue_private(c + 2);
       if (rn < m.steps) {
         const double *tl = tbuf + (size_t)tt * kSlimStepTiles;
@@ -207,7 +211,17 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
         if (tt < kXS) expand_store(xdst, kT0[tt < kXS ? tt : 0], kT1[tt < kXS ? tt : 0], x);
       }
     }
-    glds_wait();      // the prefetched raw chunk and this wave's next rows have landed ...
+    // The prefetched raw chunk (issued at the top of this chunk) and this wave's next rows (issued at
+    // K-step 4) must have landed -- but NOT the profile values requested in K-steps 4..7 for the next
+    // chunk's first four steps: vmcnt counts in order, so "at most (8 - kXS) ND operations outstanding"
+    // is exactly "everything up to the landing-zone copy has completed".  (A plain vmcnt(0) here made
+    // every wave sit out an HBM gather latency once per chunk.)  In the last chunk nothing was copied.
+#ifndef MSLIM_EXP_WAITALL
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm((CH - 4) * ND));
+    asm volatile("" ::: "memory");
+#else
+    glds_wait();
+#endif
     __syncthreads();  // ... everyone's tiles of the next chunk are written; this chunk's buffers are free
   }
 

@@ -39,6 +39,13 @@
 #include "sweep_split_kernel.hpp"
 
 namespace gpdla {
+// s_waitcnt immediate for "vmcnt(n), nothing else" (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt
+// and lgkmcnt at their maxima)
+__host__ __device__ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+static_assert(vmcnt_imm(0) == 0x0F70, "the encoding glds_wait() uses");
+}  // namespace gpdla
+
+namespace gpdla {
 
 constexpr int kS40Row = 48;                 // doubles per pixel of a record
 constexpr int kS40Rec = 4 * kS40Row;        // 192 doubles = 1536 B per K-step
@@ -329,7 +336,10 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
   };
 
   // ---- prime: raw steps 0 .. kS40Lead - 1 (role r: r, 4 + r, ...), then (w, u) of steps 0 .. 7 -----
-  [[maybe_unused]] double g_cur[2][NDR], g_next[2][NDR];
+  // multi-DLA: profile values of the two W stages of an iteration, one set per iteration parity: an
+  // iteration of parity P consumes set P and requests set P ^ 1 for the next iteration -- no register
+  // moves, and a gather has a whole iteration (8 K-steps) to land
+  [[maybe_unused]] double g_buf[2][2][NDR];
   if constexpr (!kMulti) {
     __syncthreads();  // multipliers and the exp table visible
 #pragma unroll
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
       const int t = 4 * h + role;
       double g0[NDR], w0, u0;
       gather(t, g0);
-      gather(CH + t, g_cur[h]);  // for the W stage of iteration 0
+      gather(CH + t, g_buf[0][h]);  // for the W stage of iteration 0
       weigh(t, pix_of(t), absorb_gathered(g0), &w0, &u0);
       *wu_at(0, group, 0, t) = w0;
       *wu_at(0, group, 1, t) = u0;
@@ -374,7 +384,9 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
   // requested at the top of the half.
   auto iteration = [&](auto PARC, int it) {
     constexpr int PAR = decltype(PARC)::value;
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // (see k_sweep: free here, keeps compiler waits out of the K-steps)
+    // (see k_sweep: free here, keeps compiler waits out of the K-steps; multi-DLA: the ND profile values
+    // requested in the second half of the previous iteration may still be in flight)
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(kMulti ? ND : 0));
     if (it + 1 < niter) issue_chunk(it + 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
       [[maybe_unused]] const int t_r = CH * it + kS40Lead + 4 * h + role;
       const PixelRow px_w = pix_of(t_w);
       [[maybe_unused]] double lam_r = 0.0;
-      if constexpr (kMulti) gather(t_w + CH, g_next[h]);  // for the W stage of the NEXT iteration
+      if constexpr (kMulti) gather(t_w + CH, g_buf[PAR ^ 1][h]);  // for the W stage of the NEXT iteration
       else lam_r = lam_of(t_r);
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) {
@@ -427,9 +439,7 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
 #ifndef S40_EXP_NOWR
       double w1, u1;
       if constexpr (kMulti) {
-        weigh(t_w, px_w, absorb_gathered(g_cur[h]), &w1, &u1);
-#pragma unroll
-        for (int j = 0; j < NDR; ++j) g_cur[h][j] = g_next[h][j];
+        weigh(t_w, px_w, absorb_gathered(g_buf[PAR][h]), &w1, &u1);
       } else {
         weigh(t_w, px_w, absorb_ring(t_w), &w1, &u1);
       }
@@ -440,7 +450,10 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
       asm volatile("" ::"v"(px_w.y), "v"(lam_r));
 #endif
     }
-    glds_wait();
+    // the chunk copy has landed.  Multi-DLA: the ND gathers of the second half are younger than the
+    // copy and stay in flight (the wait for that half's pixel row has already drained everything older)
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(kMulti ? ND : 0));
+    asm volatile("" ::: "memory");
 #ifndef S40_EXP_NOBAR
     __syncthreads();
 #endif

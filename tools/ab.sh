@@ -6,7 +6,7 @@
 cd "$(dirname "$0")/.."
 for round in ${AB_ROUNDS:-1 2 3}; do
   for so in build/ab/*.so; do
-    GPDLA_LIB_PATH=$PWD/$so python bench.py --no-cpu-baseline "$@" 2>/dev/null \
+    GPDLA_LIB_PATH=$PWD/$so python bench.py --no-cpu-baseline --no-mix-rider "$@" 2>/dev/null \
       | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$so', round(d['roofline']['kernel_ms'],2), round(d['roofline']['frac'],4))"
   done
 done

@@ -13,6 +13,6 @@ mkdir -p gpurun_out /tmp/ablate
 for v in ${GPDLA_ABLATE_SET:-BASE NOBARRIER NOSLOW "NOSLOW -DGPDLA_ABLATE_NOBARRIER" NOEPI NOVOIGT NOMFMA "NOSLOW -DGPDLA_ABLATE_NOEPI" "NOSLOW -DGPDLA_ABLATE_NOEPI -DGPDLA_ABLATE_NOVOIGT" "NOSLOW -DGPDLA_ABLATE_NOEPI -DGPDLA_ABLATE_NOMFMA"}; do
   name=$(echo "$v" | tr -d ' ' | sed 's/-DGPDLA_ABLATE_/+/g')
   hipcc $FLAGS -DGPDLA_ABLATE_$v $SRC -o /tmp/ablate/lib_$name.so
-  ms=$(GPDLA_EXPANDED_RECORDS=1 GPDLA_LIB_PATH=/tmp/ablate/lib_$name.so python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['roofline']['kernel_ms'])")
+  ms=$(GPDLA_EXPANDED_RECORDS=1 GPDLA_LIB_PATH=/tmp/ablate/lib_$name.so python3 bench.py --no-cpu-baseline --no-mix-rider --steps 2 --warmup 1 "$@" | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['roofline']['kernel_ms'])")
   echo "$name kernel_ms=$ms" | tee -a gpurun_out/ablate.txt
 done
