@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--total-spectra", type=int, default=162861,
                     help="dr12q-shard: quasars of the whole run, sharded over the GPUs (README.md:115)")
     ap.add_argument("--pixels", type=int, default=1500, help="configs1 only")
+    ap.add_argument("--mask-runs", action="store_true",
+                    help="dr12q-mix: the 5 %% of masked pixels in contiguous runs of 4..12 (sky lines, bad columns) "
+                         "instead of independent pixels")
     ap.add_argument("--samples", type=int, default=10000)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--contraction", choices=["f64", "f32"], default="f64",
@@ -321,7 +324,8 @@ def main():
         spectra = synthetic.make_spectra(args.spectra, args.pixels, model, first_index=args.spectra * rank)
         n_kept = np.full(args.spectra, args.pixels)
     else:
-        spectra = synthetic.make_dr12q_mix(args.spectra, model, first_index=args.spectra * rank)
+        spectra = synthetic.make_dr12q_mix(args.spectra, model, first_index=args.spectra * rank,
+                                           mask_runs=args.mask_runs)
         n_kept = synthetic.kept_pixel_counts(spectra)
     nloc = len(spectra)
     cat = synthetic.make_prior_catalog()

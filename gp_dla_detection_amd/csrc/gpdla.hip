@@ -1310,10 +1310,9 @@ int multi_alloc(gpdla_batch *b) {
     c->prof_capacity = 0;
     if ((rc = dev_alloc(&c->d_prof, need))) return rc;
     c->prof_capacity = need;
-    // touch the fresh table once: k_profiles' first launch into never-written memory ran at 2.9 TB/s
-    // against 3.5 on a table that had been written before (r03: 5.1-5.5 ms vs 4.1-4.5)
-    static const bool pretouch = std::getenv("GPDLA_NO_PROFILE_PRETOUCH") == nullptr;
-    if (pretouch) HIP_TRY(hipMemsetAsync(c->d_prof, 0, need * sizeof(double), c->stream));
+    // (Touching the fresh table once here -- a 15 GB hipMemsetAsync -- was tried in round 4 against the
+    // slower first k_profiles launch into never-written memory: no change in the call, 46.35 vs 46.34 ms,
+    // k_profiles still 4.2-5.1 ms; the memset costs what it saves.  Dropped.)
   }
   mb.prof_quasars = nq_sub;
   mb.prof_stride = stride;

@@ -554,8 +554,9 @@ class ProcessedStreamWriter:
         S, nq, B = self.S, self.nq, min(self.B, max(1, self.nq))
         self.B = B
 
-        def rows(itemsize):  # chunk extent along the sample axis
-            return max(1, min(S, self._TARGET // (itemsize * B)))
+        def rows(itemsize):  # chunk extent along the sample axis: about _TARGET bytes per chunk, and an even
+            want = max(1, min(S, self._TARGET // (itemsize * B)))  # split of S (every chunk is stored whole:
+            return -(-S // -(-S // want))                          # a ragged last chunk row would be padding)
         self.streams = {}
         try:
             if self.md:  # stored (dimension-reversed): [md, S, nq], [md - 1, S, nq], [S, nq]

@@ -122,7 +122,7 @@ def sample_dr12q_redshifts(num: int, seed: int = 4321) -> np.ndarray:
 
 
 def make_boss_spectrum(index: int, z_qso: float, model: dict, params: Parameters | None = None,
-                       mask_fraction: float = 0.05, edge_pixels: int = 2) -> dict:
+                       mask_fraction: float = 0.05, edge_pixels: int = 2, mask_runs: bool = False) -> dict:
     """One synthetic quasar on the BOSS pixel grid (log10 lambda = 3.5563 + 1e-4 j): the modelled
     rest range [911.75, 1215.75] A covers at most log10(1215.75 / 911.75) / 1e-4 = 1250 pixels and
     fewer when the spectrograph's blue edge (3600 A) cuts it (z_qso < 2.95) -- the real length mix
@@ -151,6 +151,15 @@ def make_boss_spectrum(index: int, z_qso: float, model: dict, params: Parameters
             log_nhi = float(rng.uniform(20.0, 22.0))
             flux = flux * _injected_absorption(wl, z_dla, 10.0 ** log_nhi, p.num_lines)
     mask = (rng.uniform(size=wl.size) < mask_fraction).astype(np.uint8)
+    if mask_runs:
+        # the same masked fraction in contiguous runs of 4..12 pixels, as sky-line residuals and bad
+        # columns mask a real spectrum (preload_qsos.m: BRIGHTSKY | zero inverse variance), instead of
+        # independent pixels; a separate generator, so that everything else of the spectrum is unchanged
+        r2 = np.random.default_rng(SPECTRUM_SEED0 + 104729 * 1000 + index)
+        mask = np.zeros(wl.size, dtype=np.uint8)
+        starts = np.flatnonzero(r2.uniform(size=wl.size) < mask_fraction / 8.0)
+        for s0, ln in zip(starts, r2.integers(4, 13, size=starts.size)):
+            mask[s0:s0 + ln] = 1
     nv = np.where(mask == 1, np.inf, nv)      # preload_qsos.m: zero inverse variance
     flux = np.where(mask == 1, np.nan, flux)
     return dict(wavelengths=wl, flux=flux, noise_variance=nv, pixel_mask=mask, z_qso=float(z_qso),
@@ -195,11 +204,13 @@ def make_dr12q_mix_parallel(first_index: int, num: int, k: int, workers: int, ma
 
 
 def make_dr12q_mix(num: int, model: dict, params: Parameters | None = None,
-                   mask_fraction: float = 0.05, first_index: int = 0, seed: int = 4321) -> list:
+                   mask_fraction: float = 0.05, first_index: int = 0, seed: int = 4321,
+                   mask_runs: bool = False) -> list:
     """``num`` DISTINCT quasars with the DR12Q length mix: redshifts from
-    :func:`sample_dr12q_redshifts`, spectra on the BOSS grid, 5 % of the pixels masked."""
+    :func:`sample_dr12q_redshifts`, spectra on the BOSS grid, 5 % of the pixels masked
+    (independently, or -- ``mask_runs`` -- in contiguous runs of 4..12 pixels)."""
     z = sample_dr12q_redshifts(first_index + num, seed)[first_index:]
-    return [make_boss_spectrum(first_index + i, float(z[i]), model, params, mask_fraction)
+    return [make_boss_spectrum(first_index + i, float(z[i]), model, params, mask_fraction, mask_runs=mask_runs)
             for i in range(num)]
 
 

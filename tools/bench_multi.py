@@ -60,13 +60,19 @@ gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=p)
 nb = args.pcie_batches
 big = [spectra[i % len(spectra)] for i in range(nb * args.spectra)]
 lpb = tuple(np.concatenate([np.asarray(v)] * nb, axis=0) for v in lp)
-t0 = time.perf_counter()
-gp.process_qsos_multiple_dlas_meanflux(model, samples, big, lpb, params=p, max_quasars_per_batch=args.spectra)
-pcie = (time.perf_counter() - t0) / nb
+# every call makes its own context and with it a 15 GB profile table: the first such allocations of a
+# process are slow (1.2 s, 0.8 s, then 0.3 s per call measured with tools/multi_pcie_probe.py), so the
+# call is repeated and the median reported (all three are in the line)
+pcie_calls = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    gp.process_qsos_multiple_dlas_meanflux(model, samples, big, lpb, params=p, max_quasars_per_batch=args.spectra)
+    pcie_calls.append(time.perf_counter() - t0)
+pcie = float(np.median(pcie_calls)) / nb
 flops = evals * (args.pixels * args.k * (args.k + 3) + args.k ** 3 / 3.0)
 print(json.dumps({"metric": "multi-DLA sample log-likelihoods/sec (resident in HBM)",
                   "value": evals / wall, "gpu_ms_per_call": float(np.mean(ms)), "wall_ms_per_call": wall * 1e3,
                   "algorithmic_tflops": flops / (np.mean(ms) * 1e-3) / 1e12,
-                  "pcie_inclusive_value": evals / pcie, "spectra": args.spectra, "pixels": args.pixels,
+                  "pcie_inclusive_value": evals / pcie, "pcie_inclusive_calls_s": pcie_calls, "spectra": args.spectra, "pixels": args.pixels,
                   "samples": args.samples, "max_dlas": args.max_dlas, "k": args.k, "evaluations": evals,
                   "finite_fraction": float(np.isfinite(out["sample_log_likelihoods_dla"]).mean())}))
