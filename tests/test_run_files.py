@@ -119,3 +119,54 @@ def test_ramped_blocks_cover_the_run_on_the_chunk_grid():
         assert max(hi - lo for lo, hi in blocks) <= b + grid
         if n > b and b // 8 >= 16:
             assert blocks[0][1] - blocks[0][0] == grid == b // 8 and blocks[-1][1] - blocks[-1][0] < 2 * grid
+
+
+def test_shard_workload_helpers():
+    """bench.py --workload dr12q-shard: blocks are balanced by pixel counts computed from the redshifts
+    alone -- they must be the stored lengths of the spectra the generator then makes -- and a rank's
+    block made by worker processes equals the serially made one (same seeds, same order)."""
+    model = synthetic.make_model(20)
+    z = synthetic.sample_dr12q_redshifts(300)
+    spectra = synthetic.make_dr12q_mix(300, model)
+    np.testing.assert_array_equal(synthetic.boss_pixel_counts(z), [s["wavelengths"].size for s in spectra])
+    part = synthetic.make_dr12q_mix_parallel(40, 4200, 20, workers=2)
+    assert len(part) == 4200
+    for i in (0, 1, 4199):
+        one = synthetic.make_dr12q_mix(1, model, first_index=40 + i)[0]
+        for key in ("wavelengths", "flux", "noise_variance", "pixel_mask"):
+            np.testing.assert_array_equal(part[i][key], one[key])
+        assert part[i]["z_qso"] == one["z_qso"]
+    runs = synthetic.make_dr12q_mix(50, model, mask_runs=True)  # the sky-line-style mask of the 7(b) experiment
+    frac = np.mean([s["pixel_mask"].mean() for s in runs])
+    assert 0.02 < frac < 0.08
+    for a, b in zip(runs[:5], spectra[:5]):  # only the mask (and what it blanks) differs
+        np.testing.assert_array_equal(a["wavelengths"], b["wavelengths"])
+        keep = (a["pixel_mask"] == 0) & (b["pixel_mask"] == 0)
+        np.testing.assert_array_equal(a["flux"][keep], b["flux"][keep])
+
+
+def test_staging_buffer_without_a_gpu():
+    """run_dr12q._staging: one batch's host arrays (page-locked when torch can; plain arrays here)."""
+    for md in (0, 3):
+        st = run_dr12q._staging(5, 16, md)
+        assert st["sample_log_likelihoods_dla"].shape == ((5, md, 16) if md else (5, 16))
+        assert st["sample_log_likelihoods_dla"].flags.c_contiguous and st["sample_log_likelihoods_dla"].flags.writeable
+        if md:
+            assert st["base_sample_inds"].dtype == np.uint32 and st["base_sample_inds"].shape == (5, md - 1, 16)
+            assert st["sample_log_likelihoods_lls"].shape == (5, 16)
+        st["sample_log_likelihoods_dla"][...] = 1.0
+
+
+def test_streamed_writer_chunk_rows_divide_the_sample_axis(tmp_path):
+    """Every chunk is stored whole, so a ragged last chunk row is padding on disk: the sample axis is
+    split evenly (2545-quasar batches once made a 20 358-quasar chunk file 32 % padding)."""
+    nq, S, grid = 40, 1000, 13
+    w = io.ProcessedStreamWriter(str(tmp_path / "c.mat"), nq, S, grid)
+    st = w.streams["sample_log_likelihoods_dla"][0]
+    rows = st.chunks[-2]
+    assert S % rows == 0 or (-(-S // rows)) * rows - S < -(-S // rows)  # at most one row of padding per chunk row
+    w.abort()
+    big = io.ProcessedStreamWriter(str(tmp_path / "d.mat"), 20358, 10000, 318)
+    rows = big.streams["sample_log_likelihoods_dla"][0].chunks[-2]
+    assert rows == 2500  # 8 MB / (8 B x 318) = 3297 wanted -> four equal rows instead of 3297 + 3297 + 3297 + 109
+    big.abort()
