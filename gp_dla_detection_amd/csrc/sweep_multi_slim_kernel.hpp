@@ -121,9 +121,29 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
 
   // profile values: requested kAhead K-steps before they are multiplied (the gather reads HBM)
   const int p_last = 4 * m.steps + jj;  // rows are padded to 4 (steps + 1) entries
+  // The loads are issued as inline assembly and waited for by hand (MSLIM_EXP_CLOADS: plain C++
+  // loads, for A/B).  With compiler-visible loads every K-step began with s_waitcnt vmcnt(0): the
+  // K-steps are separate basic blocks (each is guarded by rn < steps) with untracked LDS-DMA
+  // instructions between them, and the compiler's wait-count pass then no longer knows how many of
+  // its loads are in flight -- so a gather was waited for ONE K-step after its issue, not four.
+  // vmcnt counts in order: when K-step rn consumes its slot, exactly the 3 ND gathers of K-steps
+  // rn - 3 .. rn - 1 (or of the priming) are younger; DMA copies in between only make the wait stricter.
   auto gather = [&](int p, double (&r)[ND]) {
 #pragma unroll
-    for (int j = 0; j < ND; ++j) r[j] = rows[j][p];
+    for (int j = 0; j < ND; ++j) {
+#ifdef MSLIM_EXP_CLOADS
+      r[j] = rows[j][p];
+#else
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r[j]) : "v"(rows[j] + p));
+#endif
+    }
+  };
+  auto gathered = [&](double (&r)[ND]) {  // the values requested kAhead K-steps ago have arrived
+#ifndef MSLIM_EXP_CLOADS
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * ND) : "memory");
+#pragma unroll
+    for (int j = 0; j < ND; ++j) asm volatile("" : "+v"(r[j]));  // (orders every later use behind the wait)
+#endif
   };
   double raw[kAhead][ND];
 #pragma unroll
@@ -175,6 +195,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
         bop[13] = ubuf[(size_t)tt * kSlimRec];  // m[0..15] of the 4 pixels in lane order: the u tile
         // absorption of pixel 4 rn + jj: product of the gathered profiles (multi :342-351); then the
         // request for K-step rn + kAhead into the slot just consumed
+        gathered(raw[tt % kAhead]);
         double absorb = raw[tt % kAhead][0];
 #pragma unroll
         for (int j = 1; j < ND; ++j) absorb *= raw[tt % kAhead][j];
