@@ -131,7 +131,9 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
   auto gather = [&](int p, double (&r)[ND]) {
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
-#ifdef MSLIM_EXP_CLOADS
+#if defined(MSLIM_EXP_NOGATHER)
+      r[j] = 1.0 + 1e-9 * p;  // ablation: no profile loads at all (results wrong by construction)
+#elif defined(MSLIM_EXP_CLOADS)
       r[j] = rows[j][p];
 #else
       asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r[j]) : "v"(rows[j] + p));
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
     }
   };
   auto gathered = [&](double (&r)[ND]) {  // the values requested kAhead K-steps ago have arrived
-#ifndef MSLIM_EXP_CLOADS
+#if !defined(MSLIM_EXP_CLOADS) && !defined(MSLIM_EXP_NOGATHER)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kAhead - 1) * ND) : "memory");
 #pragma unroll
     for (int j = 0; j < ND; ++j) asm volatile("" : "+v"(r[j]));  // (orders every later use behind the wait)
