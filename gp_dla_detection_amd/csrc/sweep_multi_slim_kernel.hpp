@@ -248,6 +248,18 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
     __syncthreads();  // ... everyone's tiles of the next chunk are written; this chunk's buffers are free
   }
 
+  // The last four K-steps requested profile values nobody multiplies.  They were issued by inline
+  // assembly, so the compiler does not know that their destination registers are still awaited and
+  // hands them to the epilogue: a load landing late would overwrite whatever lives there by then.
+  // Drain them before anything else reuses a register.
+#if !defined(MSLIM_EXP_CLOADS) && !defined(MSLIM_EXP_NOGATHER)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < kAhead; ++t) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) asm volatile("" : "+v"(raw[t][j]));  // (the registers stay theirs up to here)
+  }
+#endif
   double logd_sum = log(dprod) + (double)dexp * 0.6931471805599453;
   quad_sum += __shfl_xor(quad_sum, 16);
   quad_sum += __shfl_xor(quad_sum, 32);
