@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "faddeeva.hpp"
 #include "near_tables.hpp"
 
@@ -807,6 +810,134 @@ __device__ __forceinline__ double factor_rows(double *e, int s, int k, int voff,
   for (int a = 1; a < ROWS; ++a)
     if (k >= LPS * a) zsel = dd[a];
   const double zz = -__shfl(zsel, k & (LPS - 1), LPS);  // z'z with z = L^-1 v
+  const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
+  const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32
+  return pd ? ll : NAN;
+}
+
+// t += (-p[lane n of this lane's 16-lane row]) * r in one instruction: the DPP form of the fp64
+// multiply-add broadcasts its first source across a row of 16 lanes (row_newbcast, the only DPP
+// control the 64-bit ALU knows).  Bit for bit fma(-p_n, r, t) and the same issue cost as the plain
+// instruction (tools/dpp_f64_probe.hip).  p must not have been written by a VALU instruction in
+// the two instructions before (DPP hazard; nothing pads inline assembly): here p always comes
+// straight from an LDS read, and tools/check_dpp_hazard.py checks the ISA of a build.
+template <int N>
+__device__ __forceinline__ void fmac_bcast(double &t, double p, double r) {
+  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(p), "v"(r), "n"(N));
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant
+// expression in the body (the DPP lane above is an instruction field)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, I...>, F &&f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
+
+// The factorisation of the 20 < k <= 40 classes: 32 lanes per sample, as factor_lds<2, 32>, but
+//   * own rows in registers (as factor_rows), and the k + 1 rows dealt in PAIRS: lane s owns rows
+//     s and k - s (s <= k/2; the other lanes idle).  factor_lds deals rows s and s + 32: its second
+//     slot holds a row in 9 of 32 lanes only, and every column costs two dot products of the
+//     column's length whichever rows are already finished.  A row is finished once the column
+//     index reaches it, so with (s, k - s) the first slot is dead in EVERY lane from column k/2 on
+//     and its dot products are not issued there: 1100 multiply-adds per pass at k = 40 against 1640;
+//   * the pivot row is not read as a broadcast.  The epilogue of these kernels is bound by the LDS
+//     return path, not by arithmetic: a ds_read2_b64 in which all lanes of a sample read the same
+//     16 bytes still returns 1 KiB, and eight waves issuing them get 171 B/clk, 48 cycles per
+//     instruction and wave (tools/dpp_f64_probe.hip).  Here lane l of each 16-lane row reads
+//     entries l, 16 + l, 32 + l of the pivot row -- one to three ds_read_b64 per pivot row instead
+//     of one read per two entries -- and the multiply-add broadcasts the entry it needs from the
+//     row's registers (fmac_bcast).
+// Columns are taken in panels of PW as in factor_lds (the part of a panel's dot products that
+// involves earlier panels needs nothing of the panel's own columns).  Entry by entry the operations
+// and their order are those of factor_lds, so results are bit-identical.
+template <int KMAX, int PW>
+__device__ __forceinline__ double factor_paired(double *e, int s, int k, int voff, double q_s, double ld_s,
+                                                int n_kept) {
+  static_assert(KMAX % PW == 0 && PW <= 16 && KMAX <= 48, "whole panels; three registers per pivot row");
+  constexpr int K0 = (KMAX / 2 + PW - 1) / PW * PW;  // slot 0 holds rows < ceil(k/2): its columns, in whole panels
+  const bool has0 = 2 * s < k, has1 = 2 * s <= k;
+  const int i0 = has0 ? s : k + 1, i1 = has1 ? k - s : k + 1;  // (k + 1: no row; reads alias v, never written)
+  const int ro0 = i0 < k ? i0 * (i0 + 1) / 2 : voff, ro1 = i1 < k ? i1 * (i1 + 1) / 2 : voff;
+  double dd0 = i0 < k ? e[ro0 + i0] + 1.0 : 0.0;   // log_mvnpdf_low_rank.m:22-23
+  double dd1 = i1 < k ? e[ro1 + i1] + 1.0 : 0.0;
+  double rc0[K0], rc1[KMAX];  // entry (row, column m): A before column m, L after
+#pragma unroll
+  for (int m = 0; m < K0; ++m) rc0[m] = e[ro0 + m];
+#pragma unroll
+  for (int m = 0; m < KMAX; ++m) rc1[m] = e[ro1 + m];  // (columns >= the row index: unused)
+  // this lane's window on a pivot row: entry (s & 15) + 16 r of row j is el[j (j + 1) / 2 + 16 r]
+  // (immediate offsets of one address register; a row's tail reads into the next rows, in bounds)
+  const __attribute__((address_space(3))) double *el =
+      (const __attribute__((address_space(3))) double *)(uintptr_t)lds_address(e + (s & 15));
+  double lprod = 1.0;
+  int lexp = 0;
+  bool pd = true;
+  static_for<KMAX / PW>([&](auto P_) __attribute__((always_inline)) {
+    constexpr int j0 = decltype(P_)::value * PW;
+    if (j0 < k) {  // block-uniform
+      // (panels j0 < K0 carry both slots whatever k is: for k < KMAX the first slot's rows may all be
+      // finished earlier, and what is computed for them then is never stored)
+      constexpr bool two = j0 < K0;
+      constexpr int NR = (j0 + 15) / 16;  // registers of a pivot row that hold columns < j0
+      double pb[PW][3], t0[PW], t1[PW];
+#pragma unroll
+      for (int c = 0; c < PW; ++c) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pb[c][r] = r < NR ? el[(j0 + c) * (j0 + c + 1) / 2 + 16 * r] : 0.0;
+        t1[c] = rc1[j0 + c];
+        t0[c] = two ? rc0[two ? j0 + c : 0] : 0.0;
+      }
+      static_for<j0>([&](auto M_) __attribute__((always_inline)) {
+        constexpr int mm = decltype(M_)::value;
+        static_for<PW>([&](auto C_) __attribute__((always_inline)) {
+          constexpr int c = decltype(C_)::value;
+          if constexpr (two) fmac_bcast<mm % 16>(t0[c], pb[c][mm / 16], rc0[mm < K0 ? mm : 0]);
+          fmac_bcast<mm % 16>(t1[c], pb[c][mm / 16], rc1[mm]);
+        });
+      });
+      static_for<PW>([&](auto C_) __attribute__((always_inline)) {
+        constexpr int c = decltype(C_)::value, j = j0 + c;
+        if (j < k) {  // block-uniform
+          if constexpr (c > 0) {  // in-panel terms: columns j0 .. j - 1 of row j, stored by the previous column steps
+            const double pin = el[j * (j + 1) / 2 + j0];
+            static_for<c>([&](auto Q_) __attribute__((always_inline)) {
+              constexpr int cp = decltype(Q_)::value;
+              fmac_bcast<cp>(t1[c], pin, t1[cp]);
+              if constexpr (two) fmac_bcast<cp>(t0[c], pin, t0[cp]);
+            });
+          }
+          const bool low = 2 * j < k;  // row j lives in slot 0 of lane j, else in slot 1 of lane k - j
+          const double dj = __shfl(low ? dd0 : dd1, low ? j : k - j, 32);  // pivot
+          pd = pd && (dj > 0.0);                         // chol would throw here (:24)
+          const double inv = rsqrt_nr(dj);
+          lprod *= dj;                                   // 2 Sum log L_jj = log Prod d_j (:30)
+          lexp += __builtin_amdgcn_frexp_exp(lprod);
+          lprod = __builtin_amdgcn_frexp_mant(lprod);
+          t1[c] *= inv;
+          rc1[j] = t1[c];
+          if (i1 > j && i1 <= k) {
+            e[ro1 + j] = t1[c];                          // row i1 becomes a pivot row later
+            dd1 = fma(-t1[c], t1[c], dd1);
+          }
+          if constexpr (two) {
+            t0[c] *= inv;
+            rc0[j] = t0[c];
+            if (i0 > j && i0 <= k) {
+              e[ro0 + j] = t0[c];
+              dd0 = fma(-t0[c], t0[c], dd0);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      });
+    }
+  });
+  const double zz = -__shfl(dd1, 0, 32);  // row k is slot 1 of lane 0: -dd ends as z'z with z = L^-1 v
   const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
   const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32
   return pd ? ll : NAN;

@@ -38,6 +38,10 @@
 #include "multi_kernels.hpp"
 #include "sweep_split_kernel.hpp"
 
+#ifndef S40_EPI_PW
+#define S40_EPI_PW 4  // columns per panel of the epilogue's factorisation (factor_paired)
+#endif
+
 namespace gpdla {
 // s_waitcnt immediate for "vmcnt(n), nothing else" (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt
 // and lgkmcnt at their maxima)
@@ -493,16 +497,31 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
 #pragma unroll
   for (int cc = 0; cc < NTW; ++cc) at[cc] = s40_pos(wave_s * NTW + cc, s);
   double *Eg = stage;
+  // The second pass's result registers wait in scratch while the first pass factors: factor_paired
+  // keeps 2 x 60 row entries per lane in registers, which together with 112 live accumulator
+  // registers is more than a wave has -- and left to itself the register allocator spills the row
+  // entries (1600 scratch accesses inside the factorisation) rather than the accumulators (56 stores,
+  // 56 loads).  The array's address escapes, so it stays in memory.
+  double keep[4 * NTW];
+#pragma unroll
+  for (int cc = 0; cc < NTW; ++cc) {
+    keep[4 * cc + 0] = acc0[cc][2];
+    keep[4 * cc + 1] = acc0[cc][3];
+    keep[4 * cc + 2] = acc1[cc][2];
+    keep[4 * cc + 3] = acc1[cc][3];
+  }
+  asm volatile("" ::"v"(&keep[0]) : "memory");
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     __syncthreads();  // previous pass factored (and, for p = 0, the loop's buffers are dead)
     double *e0 = Eg + (size_t)(jj * 2) * ncols, *e1 = e0 + (size_t)ES::SPP * ncols;
+    if (p == 1) asm volatile("" ::"v"(&keep[0]) : "memory");
 #pragma unroll
     for (int cc = 0; cc < NTW; ++cc) {
-      e0[at[cc]] = acc0[cc][2 * p];
-      e0[ncols + at[cc]] = acc0[cc][2 * p + 1];
-      e1[at[cc]] = acc1[cc][2 * p];
-      e1[ncols + at[cc]] = acc1[cc][2 * p + 1];
+      e0[at[cc]] = p ? keep[4 * cc + 0] : acc0[cc][0];
+      e0[ncols + at[cc]] = p ? keep[4 * cc + 1] : acc0[cc][1];
+      e1[at[cc]] = p ? keep[4 * cc + 2] : acc1[cc][0];
+      e1[ncols + at[cc]] = p ? keep[4 * cc + 3] : acc1[cc][1];
     }
     __syncthreads();
     const int rho = 2 * role + (lane >> 5);
@@ -510,8 +529,11 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
     const double q_s = __shfl(quad_sum, sigma), ld_s = __shfl(logd_sum, sigma);
 #ifdef S40_EXP_NOEPI
     const double ll = q_s + ld_s + Eg[(size_t)(group * ES::SPP + rho) * ncols + (lane & 31)];
-#else
+#elif defined(S40_EXP_LDSEPI)
     const double ll = factor_lds<2, 32>(Eg + (size_t)(group * ES::SPP + rho) * ncols, lane & 31, a.k, voff, q_s, ld_s,
+                                        m.n_kept);
+#else
+    const double ll = factor_paired<40, S40_EPI_PW>(Eg + (size_t)(group * ES::SPP + rho) * ncols, lane & 31, a.k, voff, q_s, ld_s,
                                         m.n_kept);
 #endif
     const int64_t slot_s = slot0 + sigma;
