@@ -826,6 +826,14 @@ __device__ __forceinline__ void fmac_bcast(double &t, double p, double r) {
   asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(p), "v"(r), "n"(N));
 }
 
+// p[lane N of this lane's 16-lane row] (same hazard rule)
+template <int N>
+__device__ __forceinline__ double mov_bcast(double p) {
+  double d;
+  asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(p), "n"(N));
+  return d;
+}
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant
 // expression in the body (the DPP lane above is an instruction field)
 template <int... I, typename F>
@@ -860,15 +868,28 @@ __device__ __forceinline__ double factor_paired(double *e, int s, int k, int vof
   static_assert(KMAX % PW == 0 && PW <= 16 && KMAX <= 48, "whole panels; three registers per pivot row");
   constexpr int K0 = (KMAX / 2 + PW - 1) / PW * PW;  // slot 0 holds rows < ceil(k/2): its columns, in whole panels
   const bool has0 = 2 * s < k, has1 = 2 * s <= k;
-  const int i0 = has0 ? s : k + 1, i1 = has1 ? k - s : k + 1;  // (k + 1: no row; reads alias v, never written)
-  const int ro0 = i0 < k ? i0 * (i0 + 1) / 2 : voff, ro1 = i1 < k ? i1 * (i1 + 1) / 2 : voff;
-  double dd0 = i0 < k ? e[ro0 + i0] + 1.0 : 0.0;   // log_mvnpdf_low_rank.m:22-23
-  double dd1 = i1 < k ? e[ro1 + i1] + 1.0 : 0.0;
+  const int i0 = has0 ? s : -1, i1 = has1 ? k - s : -1;  // (-1: no row; its reads alias v, it is never written)
+  const int ro0 = has0 ? i0 * (i0 + 1) / 2 : voff, ro1 = has1 && i1 < k ? i1 * (i1 + 1) / 2 : voff;
+  // Where the lane keeps the running diagonal dd_i = A_ii + 1 - Sum_{m<j} l_im^2 of each of its rows
+  // for the others to see: the row's own diagonal slot.  It is stored after every column, finished
+  // or not -- nobody reads a finished row's slot -- so the pivot of column j is simply entry j of
+  // row j when the column's step reads that row (no shuffle, no select between the two slots).  Row k
+  // (v) has no diagonal slot and is nobody's pivot.
+  const bool pub0 = has0, pub1 = has1 && i1 < k;
+  const int dg0 = ro0 + i0, dg1 = ro1 + i1;
+  double dd0 = pub0 ? e[dg0] + 1.0 : 0.0;   // log_mvnpdf_low_rank.m:22-23
+  double dd1 = pub1 ? e[dg1] + 1.0 : 0.0;
   double rc0[K0], rc1[KMAX];  // entry (row, column m): A before column m, L after
 #pragma unroll
   for (int m = 0; m < K0; ++m) rc0[m] = e[ro0 + m];
 #pragma unroll
   for (int m = 0; m < KMAX; ++m) rc1[m] = e[ro1 + m];  // (columns >= the row index: unused)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // (every lane has read its A_ii before anybody overwrites one)
+  if (pub0) e[dg0] = dd0;
+  if (pub1) e[dg1] = dd1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   // this lane's window on a pivot row: entry (s & 15) + 16 r of row j is el[j (j + 1) / 2 + 16 r]
   // (immediate offsets of one address register; a row's tail reads into the next rows, in bounds)
   const __attribute__((address_space(3))) double *el =
@@ -883,53 +904,49 @@ __device__ __forceinline__ double factor_paired(double *e, int s, int k, int vof
       // finished earlier, and what is computed for them then is never stored)
       constexpr bool two = j0 < K0;
       constexpr int NR = (j0 + 15) / 16;  // registers of a pivot row that hold columns < j0
-      double pb[PW][3], t0[PW], t1[PW];
+      double pb[PW][3];
 #pragma unroll
-      for (int c = 0; c < PW; ++c) {
+      for (int c = 0; c < PW; ++c)
 #pragma unroll
         for (int r = 0; r < 3; ++r) pb[c][r] = r < NR ? el[(j0 + c) * (j0 + c + 1) / 2 + 16 * r] : 0.0;
-        t1[c] = rc1[j0 + c];
-        t0[c] = two ? rc0[two ? j0 + c : 0] : 0.0;
-      }
       static_for<j0>([&](auto M_) __attribute__((always_inline)) {
         constexpr int mm = decltype(M_)::value;
         static_for<PW>([&](auto C_) __attribute__((always_inline)) {
           constexpr int c = decltype(C_)::value;
-          if constexpr (two) fmac_bcast<mm % 16>(t0[c], pb[c][mm / 16], rc0[mm < K0 ? mm : 0]);
-          fmac_bcast<mm % 16>(t1[c], pb[c][mm / 16], rc1[mm]);
+          if constexpr (two) fmac_bcast<mm % 16>(rc0[two ? j0 + c : 0], pb[c][mm / 16], rc0[mm < K0 ? mm : 0]);
+          fmac_bcast<mm % 16>(rc1[j0 + c], pb[c][mm / 16], rc1[mm]);
         });
       });
       static_for<PW>([&](auto C_) __attribute__((always_inline)) {
         constexpr int c = decltype(C_)::value, j = j0 + c;
         if (j < k) {  // block-uniform
-          if constexpr (c > 0) {  // in-panel terms: columns j0 .. j - 1 of row j, stored by the previous column steps
-            const double pin = el[j * (j + 1) / 2 + j0];
-            static_for<c>([&](auto Q_) __attribute__((always_inline)) {
-              constexpr int cp = decltype(Q_)::value;
-              fmac_bcast<cp>(t1[c], pin, t1[cp]);
-              if constexpr (two) fmac_bcast<cp>(t0[c], pin, t0[cp]);
-            });
-          }
-          const bool low = 2 * j < k;  // row j lives in slot 0 of lane j, else in slot 1 of lane k - j
-          const double dj = __shfl(low ? dd0 : dd1, low ? j : k - j, 32);  // pivot
+          // columns j0 .. j0 + 15 of row j: the entries the previous column steps of this panel
+          // stored (the in-panel terms), and at column j the row's running diagonal, i.e. the pivot
+          const double pin = el[j * (j + 1) / 2 + j0];
+          static_for<c>([&](auto Q_) __attribute__((always_inline)) {
+            constexpr int cp = decltype(Q_)::value;
+            fmac_bcast<cp>(rc1[j], pin, rc1[j0 + cp]);
+            if constexpr (two) fmac_bcast<cp>(rc0[two ? j : 0], pin, rc0[two ? j0 + cp : 0]);
+          });
+          const double dj = mov_bcast<c>(pin);
           pd = pd && (dj > 0.0);                         // chol would throw here (:24)
           const double inv = rsqrt_nr(dj);
           lprod *= dj;                                   // 2 Sum log L_jj = log Prod d_j (:30)
-          lexp += __builtin_amdgcn_frexp_exp(lprod);
-          lprod = __builtin_amdgcn_frexp_mant(lprod);
-          t1[c] *= inv;
-          rc1[j] = t1[c];
-          if (i1 > j && i1 <= k) {
-            e[ro1 + j] = t1[c];                          // row i1 becomes a pivot row later
-            dd1 = fma(-t1[c], t1[c], dd1);
+          if constexpr (c == PW - 1) {  // (scaling by powers of two is exact: once per panel is the same product)
+            lexp += __builtin_amdgcn_frexp_exp(lprod);
+            lprod = __builtin_amdgcn_frexp_mant(lprod);
           }
+          int jc = j;  // (opaque: or all k compares are formed up front and their masks spilled)
+          asm volatile("" : "+s"(jc)::"memory");
+          rc1[j] *= inv;
+          if (i1 > jc) e[ro1 + j] = rc1[j];              // row i1 becomes a pivot row later
+          dd1 = fma(-rc1[j], rc1[j], dd1);               // (a finished row's dd is dead)
+          if (pub1) e[dg1] = dd1;
           if constexpr (two) {
-            t0[c] *= inv;
-            rc0[j] = t0[c];
-            if (i0 > j && i0 <= k) {
-              e[ro0 + j] = t0[c];
-              dd0 = fma(-t0[c], t0[c], dd0);
-            }
+            rc0[two ? j : 0] *= inv;
+            if (i0 > jc) e[ro0 + j] = rc0[two ? j : 0];
+            dd0 = fma(-rc0[two ? j : 0], rc0[two ? j : 0], dd0);
+            if (pub0) e[dg0] = dd0;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -937,6 +954,8 @@ __device__ __forceinline__ double factor_paired(double *e, int s, int k, int vof
       });
     }
   });
+  lexp += __builtin_amdgcn_frexp_exp(lprod);  // (k need not end a panel)
+  lprod = __builtin_amdgcn_frexp_mant(lprod);
   const double zz = -__shfl(dd1, 0, 32);  // row k is slot 1 of lane 0: -dd ends as z'z with z = L^-1 v
   const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
   const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32

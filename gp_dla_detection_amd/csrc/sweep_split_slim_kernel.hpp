@@ -497,31 +497,35 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
 #pragma unroll
   for (int cc = 0; cc < NTW; ++cc) at[cc] = s40_pos(wave_s * NTW + cc, s);
   double *Eg = stage;
-  // The second pass's result registers wait in scratch while the first pass factors: factor_paired
-  // keeps 2 x 60 row entries per lane in registers, which together with 112 live accumulator
-  // registers is more than a wave has -- and left to itself the register allocator spills the row
-  // entries (1600 scratch accesses inside the factorisation) rather than the accumulators (56 stores,
-  // 56 loads).  The array's address escapes, so it stays in memory.
-  double keep[4 * NTW];
+  double *e0 = Eg + (size_t)(jj * 2) * ncols, *e1 = e0 + (size_t)ES::SPP * ncols;
+  __syncthreads();  // the loop's buffers are dead
 #pragma unroll
   for (int cc = 0; cc < NTW; ++cc) {
-    keep[4 * cc + 0] = acc0[cc][2];
-    keep[4 * cc + 1] = acc0[cc][3];
-    keep[4 * cc + 2] = acc1[cc][2];
-    keep[4 * cc + 3] = acc1[cc][3];
+    e0[at[cc]] = acc0[cc][0];
+    e0[ncols + at[cc]] = acc0[cc][1];
+    e1[at[cc]] = acc1[cc][0];
+    e1[ncols + at[cc]] = acc1[cc][1];
   }
-  asm volatile("" ::"v"(&keep[0]) : "memory");
+  // ONE copy of the factorisation's straight-line code (4 to 6 thousand instructions).  The first
+  // pass's spill is peeled off above, so only the second pass's result registers (56 of the 112) are
+  // live while the first pass factors; with the 60 row entries per lane factor_paired keeps that
+  // still fits the register file -- nothing of the epilogue may go to scratch: 100 bytes per lane
+  // and block would already double the kernel's HBM traffic
+#ifdef S40_EXP_UNROLLP
 #pragma unroll
+#else
+#pragma nounroll
+#endif
   for (int p = 0; p < 2; ++p) {
-    __syncthreads();  // previous pass factored (and, for p = 0, the loop's buffers are dead)
-    double *e0 = Eg + (size_t)(jj * 2) * ncols, *e1 = e0 + (size_t)ES::SPP * ncols;
-    if (p == 1) asm volatile("" ::"v"(&keep[0]) : "memory");
+    if (p == 1) {
+      __syncthreads();  // first pass factored
 #pragma unroll
-    for (int cc = 0; cc < NTW; ++cc) {
-      e0[at[cc]] = p ? keep[4 * cc + 0] : acc0[cc][0];
-      e0[ncols + at[cc]] = p ? keep[4 * cc + 1] : acc0[cc][1];
-      e1[at[cc]] = p ? keep[4 * cc + 2] : acc1[cc][0];
-      e1[ncols + at[cc]] = p ? keep[4 * cc + 3] : acc1[cc][1];
+      for (int cc = 0; cc < NTW; ++cc) {
+        e0[at[cc]] = acc0[cc][2];
+        e0[ncols + at[cc]] = acc0[cc][3];
+        e1[at[cc]] = acc1[cc][2];
+        e1[ncols + at[cc]] = acc1[cc][3];
+      }
     }
     __syncthreads();
     const int rho = 2 * role + (lane >> 5);

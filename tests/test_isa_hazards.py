@@ -1,0 +1,49 @@
+"""The DPP read hazard around the inline-assembly v_fmac_f64_dpp / v_mov_b64_dpp of factor_paired
+(csrc/sweep_kernels.hpp) is the compiler's to pad for its own instructions but nobody's for inline
+assembly.  tools/check_dpp_hazard.py scans an ISA dump for it; here it is run on a build of the
+shipped source (hipcc cross-compiles without a GPU) and on two hand-made cases."""
+import glob
+import importlib.util
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _checker():
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "tools", "check_dpp_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+DPP = "\tv_fmac_f64_dpp v[4:5], -v[0:1], v[2:3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+
+
+def test_checker_sees_a_hazard_and_accepts_padding(tmp_path, capsys):
+    chk = _checker()
+    bad = tmp_path / "bad.s"
+    bad.write_text("\tv_mov_b64_e32 v[0:1], v[8:9]\n\ts_nop 0\n" + DPP)
+    assert chk.main(str(bad)) == 1
+    ok = tmp_path / "ok.s"
+    ok.write_text("\tv_mul_f64 v[0:1], v[2:3], v[2:3]\n\ts_nop 1\n" + DPP + "\tds_read_b64 v[0:1], v9\n\ts_waitcnt lgkmcnt(0)\n" + DPP)
+    assert chk.main(str(ok)) == 0
+    cmpx = tmp_path / "cmpx.s"
+    cmpx.write_text("\tv_cmpx_lt_i32_e32 v1, v2\n\ts_nop 2\n" + DPP)
+    assert chk.main(str(cmpx)) == 1
+    capsys.readouterr()
+
+
+def test_shipped_kernels_have_no_dpp_hazard(tmp_path, capsys):
+    sys.path.insert(0, ROOT)
+    from gp_dla_detection_amd import _lib
+    out = tmp_path / "libgpdla_isa.so"
+    subprocess.check_call(["hipcc", *_lib.HIPCC_FLAGS, "-save-temps=obj", os.path.join(_lib.CSRC, "gpdla.hip"), "-o", str(out)],
+                          cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dumps = glob.glob(str(tmp_path / "*gfx950*.s"))
+    assert len(dumps) == 1, dumps
+    text = open(dumps[0]).read()
+    assert text.count("v_fmac_f64_dpp") > 1000 and "v_mov_b64_dpp" in text  # (the check below is not vacuous)
+    assert _checker().main(dumps[0]) == 0, capsys.readouterr().out
+    capsys.readouterr()

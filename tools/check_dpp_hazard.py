@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Checks a gfx950 ISA dump (hipcc -save-temps, *.s) for the DPP read hazard around inline-assembly
-v_fmac_f64_dpp instructions (csrc/sweep_kernels.hpp: fmac_bcast).
+v_fmac_f64_dpp / v_mov_b64_dpp instructions (csrc/sweep_kernels.hpp: fmac_bcast, mov_bcast).
 
 gfx9 rule: a DPP instruction must not read a VGPR that a VALU instruction wrote less than 2 wait
 states earlier, nor follow a VALU write of EXEC by less than 5.  The compiler pads the instructions
@@ -31,7 +31,7 @@ def main(path):
         parts = text.split(None, 1)
         op = parts[0]
         ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
-        if op == "v_fmac_f64_dpp":
+        if op.endswith("_dpp"):
             checked += 1
             src0 = regs(ops[1].split()[0])
             states = 0
@@ -54,7 +54,7 @@ def main(path):
         window.append((took, wrote, wrote_exec, text))
         if len(window) > 8:
             window.pop(0)
-    print(f"{checked} v_fmac_f64_dpp checked, {bad} hazard(s)")
+    print(f"{checked} DPP instructions checked, {bad} hazard(s)")
     return 1 if bad else 0
 
 

@@ -1,6 +1,6 @@
 // Probes behind the epilogue of the 20 < k <= 40 sweeps (factor_paired):
 //   1. does v_fmac_f64_dpp with row_newbcast:n compute  d += (-s0[lane n of the 16-lane row]) * s1  bit for bit
-//      like fma(-s0[16 row + n], s1, d) ?
+//      like fma(-s0[16 row + n], s1, d) ?  (and v_mov_b64_dpp: the plain broadcast)
 //   2. issue cost of that instruction against plain v_fmac_f64 (four independent chains, one wave)
 //   3. dependent-issue cost of v_fma_f64 (ONE chain, one wave) -- what a single dot-product chain pays
 //   4. cost of a broadcast ds_read2_b64 (all lanes of a half wave read the same 16 bytes) with one
@@ -18,6 +18,9 @@ __global__ void semantics(double *out, const double *d, const double *s0, const 
   double t = d[threadIdx.x], p = s0[threadIdx.x], r = s1[threadIdx.x];
   asm volatile("s_nop 4\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(p), "v"(r), "n"(N));
   out[N * 64 + threadIdx.x] = t;
+  double bc;
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(bc) : "v"(p), "n"(N));
+  out[(16 + N) * 64 + threadIdx.x] = bc;
 }
 
 template <int OP>
@@ -68,7 +71,7 @@ int main() {
   hipMalloc(&out, 1 << 20);
   hipMalloc(&din, 3 * 64 * 8);
   hipMalloc(&cyc, 8);
-  double hd[3 * 64], ho[16 * 64];
+  double hd[3 * 64], ho[32 * 64];
   for (int i = 0; i < 64; ++i) {
     hd[i] = 0.3 + 0.01 * i;
     hd[64 + i] = 1.0 / 3.0 + 0.1 * i;
@@ -85,6 +88,11 @@ int main() {
       if (memcmp(&want, &ho[n * 64 + l], 8)) ++bad;
     }
   printf("v_fmac_f64_dpp -s0 row_newbcast:n == fma(-s0[16 row + n], s1, d): %s (%d of 1024 lanes differ)\n", bad ? "NO" : "bit for bit", bad);
+  bad = 0;
+  for (int n = 0; n < 16; ++n)
+    for (int l = 0; l < 64; ++l)
+      if (memcmp(&hd[64 + (l & ~15) + n], &ho[(16 + n) * 64 + l], 8)) ++bad;
+  printf("v_mov_b64_dpp row_newbcast:n == s0[16 row + n]: %s (%d of 1024 lanes differ)\n", bad ? "NO" : "yes", bad);
   const char *names[] = {"v_fmac_f64 x4 chains", "v_fmac_f64_dpp x4 chains", "v_fma_f64 one chain", "v_fmac_f64_dpp one chain"};
 #define RUN(OP)                                                                 \
   hipLaunchKernelGGL(rate<OP>, dim3(1), dim3(64), 0, 0, out, cyc, 1.25, 0.75);  \
