@@ -270,7 +270,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mix-rider", action="store_true",
                     help="configs1 at N = 1 also times ONE launch of the dr12q-mix shape after the timed "
-                         "region (config.dr12q_mix, never value); this skips it")
+                         "region (config.dr12q_mix, never value), and one of 256 quasars at k = 40 (config.k40); "
+                         "this skips both")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the one-shot host-buffer entry point (H2D + sweep + D2H); "
                          "reported as config.pcie_inclusive_evals_per_s, never as value")
@@ -532,6 +533,29 @@ def main():
                 "achieved_tflops": fl / (ms_mix * 1e-3) / 1e12, "frac": fl / (ms_mix * 1e-3) / 1e12 / peak,
                 "kept_pixels_mean": float(kept.mean())}
             bm.close()
+            # ... and the 20 < k <= 40 class (BASELINE configs[3]/[4] territory): ONE launch of 256 quasars
+            # x 1500 px at k = 40 through a second context, timed the same way; never `value`
+            model40 = synthetic.make_model(40)
+            sp40 = synthetic.make_spectra(256, args.pixels, model40, first_index=7000)
+            z40 = np.array([s_["z_qso"] for s_ in sp40])
+            lp40 = gp.dla_existence_prior(cat["z_qsos"], cat["dla_ind"], z40)
+            ctx40 = gp.Context(local_rank, params=params, stream=stream)
+            ctx40.set_model(model40)
+            ctx40.set_samples(samples)
+            ctx40.set_timing(True)
+            b40 = ctx40.upload(sp40, lp40[0], lp40[1])
+            with torch.cuda.stream(stream):
+                b40.process()
+                b40.process()
+                ms40 = ctx40.last_sweep_ms()
+            fl40 = 256 * algorithmic_flops(float(args.pixels), 40) * args.samples
+            out["config"]["k40"] = {
+                "what": f"one k_sweep_split_slim launch over 256 distinct quasars x {args.pixels} px at k = 40, after the "
+                        "timed region; kernel-timed, never `value`",
+                "kernel_ms": ms40, "evals_per_s": 256 * args.samples / (ms40 * 1e-3),
+                "achieved_tflops": fl40 / (ms40 * 1e-3) / 1e12, "frac": fl40 / (ms40 * 1e-3) / 1e12 / peak}
+            b40.close()
+            ctx40.close()
         if world == 1 and not args.no_cpu_baseline and not shard:
             checked, out["cpu_baseline"] = cpu_baseline(model, samples, spectra)
             # the quasars the oracle has just swept (all S samples each), against the timed GPU batch:
