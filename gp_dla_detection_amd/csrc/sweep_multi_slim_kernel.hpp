@@ -193,8 +193,13 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
         const double py = p01.x, pmu = p01.y, pom = p23.x, pnu = p23.y;
         double bop[14];
 #pragma unroll
+#ifdef MSLIM_EXP_NOBOP  // ablation: no fragment reads (results wrong by construction)
+        for (int cc = 0; cc < 14; ++cc) bop[cc] = 1.0 + 1e-9 * (cc + lane);
+        asm volatile("" ::"v"(tl));
+#else
         for (int cc = 0; cc < kSlimTilesW; ++cc) bop[cc] = tl[cc * 64];
         bop[13] = ubuf[(size_t)tt * kSlimRec];  // m[0..15] of the 4 pixels in lane order: the u tile
+#endif
         // absorption of pixel 4 rn + jj: product of the gathered profiles (multi :342-351); then the
         // request for K-step rn + kAhead into the slot just consumed
         gathered(raw[tt % kAhead]);
@@ -245,7 +250,9 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
 #else
     glds_wait();
 #endif
+#ifndef MSLIM_EXP_NOBAR  // (ablation: no chunk barrier; results wrong by construction)
     __syncthreads();  // ... everyone's tiles of the next chunk are written; this chunk's buffers are free
+#endif
   }
 
   // The last four K-steps requested profile values nobody multiplies.  They were issued by inline
@@ -282,7 +289,15 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
   for (int p = 0; p < ES::PASSES; ++p) {
     int sigma;
     bool writer;
+#ifdef MSLIM_EXP_NOEPI  // ablation: no factorisation (results wrong by construction)
+    sigma = (lane >> 4) + 4 * (2 * p + ((lane >> 3) & 1));
+    writer = (lane & 7) == 0;
+    double ll = quad_sum + logd_sum + xw[0] + xu[p];
+#pragma unroll
+    for (int cc = 0; cc < 14; ++cc) ll += acc[cc][2 * p] + acc[cc][2 * p + 1];  // (every accumulator stays live)
+#else
     const double ll = slim_factor_pass(acc, xw, xu, p, Eg, lane, a.k, quad_sum, logd_sum, m.n_kept, &sigma, &writer);
+#endif
     const int64_t slot_s = slot0 + sigma;
     const bool ok_s = __shfl(chain_ok, sigma) != 0;  // lane sigma (jj = 0) holds sample sigma's flag
     if (writer) {
