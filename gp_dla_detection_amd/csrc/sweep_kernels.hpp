@@ -846,12 +846,14 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 // The factorisation of the 20 < k <= 40 classes: 32 lanes per sample, as factor_lds<2, 32>, but
-//   * own rows in registers (as factor_rows), and the k + 1 rows dealt in PAIRS: lane s owns rows
-//     s and k - s (s <= k/2; the other lanes idle).  factor_lds deals rows s and s + 32: its second
-//     slot holds a row in 9 of 32 lanes only, and every column costs two dot products of the
-//     column's length whichever rows are already finished.  A row is finished once the column
-//     index reaches it, so with (s, k - s) the first slot is dead in EVERY lane from column k/2 on
-//     and its dot products are not issued there: 1100 multiply-adds per pass at k = 40 against 1640;
+//   * own rows in registers (as factor_rows), and the k + 1 rows dealt so that the SHORT rows share
+//     lanes with long ones: lane s owns row R0 + s (R0 = KMAX - 31 = 9), and lanes 0 .. R0 - 1 own
+//     rows 0 .. R0 - 1 as well.  factor_lds deals rows s and s + 32: its second slot holds a row in 9 of
+//     32 lanes only, and every column costs two dot products of the column's length whichever rows
+//     are already finished.  A row is finished once the column index reaches it, so here the second
+//     slot is dead in EVERY lane from column R0 - 1 on and its dot products are not issued there:
+//     808 multiply-adds per pass at k = 40 against 1640 (a first version paired rows s and k - s:
+//     970);
 //   * the pivot row is not read as a broadcast.  The epilogue of these kernels is bound by the LDS
 //     return path, not by arithmetic: a ds_read2_b64 in which all lanes of a sample read the same
 //     16 bytes still returns 1 KiB, and eight waves issuing them get 171 B/clk, 48 cycles per
@@ -861,14 +863,17 @@ __device__ __forceinline__ void static_for(F &&f) {
 //     row's registers (fmac_bcast).
 // Columns are taken in panels of PW as in factor_lds (the part of a panel's dot products that
 // involves earlier panels needs nothing of the panel's own columns).  Entry by entry the operations
-// and their order are those of factor_lds, so results are bit-identical.
+// and their order are those of factor_lds, so results are bit-identical.  (The name is the first
+// version's.)
 template <int KMAX, int PW>
 __device__ __forceinline__ double factor_paired(double *e, int s, int k, int voff, double q_s, double ld_s,
                                                 int n_kept) {
   static_assert(KMAX % PW == 0 && PW <= 16 && KMAX <= 48, "whole panels; three registers per pivot row");
-  constexpr int K0 = (KMAX / 2 + PW - 1) / PW * PW;  // slot 0 holds rows < ceil(k/2): its columns, in whole panels
-  const bool has0 = 2 * s < k, has1 = 2 * s <= k;
-  const int i0 = has0 ? s : -1, i1 = has1 ? k - s : -1;  // (-1: no row; its reads alias v, it is never written)
+  constexpr int R0 = KMAX + 1 - 32;                   // rows 0 .. R0 - 1 are the second rows of lanes 0 .. R0 - 1
+  constexpr int K0 = (R0 - 1 + PW - 1) / PW * PW;     // ... and need columns < R0 - 1, in whole panels
+  static_assert(R0 >= 1 && R0 <= 32, "two rows per lane at most");
+  const bool has0 = s < R0 && s < k, has1 = R0 + s <= k;
+  const int i0 = has0 ? s : -1, i1 = has1 ? R0 + s : -1;  // (-1: no row; its reads alias v, it is never written)
   const int ro0 = has0 ? i0 * (i0 + 1) / 2 : voff, ro1 = has1 && i1 < k ? i1 * (i1 + 1) / 2 : voff;
   // Where the lane keeps the running diagonal dd_i = A_ii + 1 - Sum_{m<j} l_im^2 of each of its rows
   // for the others to see: the row's own diagonal slot.  It is stored after every column, finished
@@ -900,8 +905,7 @@ __device__ __forceinline__ double factor_paired(double *e, int s, int k, int vof
   static_for<KMAX / PW>([&](auto P_) __attribute__((always_inline)) {
     constexpr int j0 = decltype(P_)::value * PW;
     if (j0 < k) {  // block-uniform
-      // (panels j0 < K0 carry both slots whatever k is: for k < KMAX the first slot's rows may all be
-      // finished earlier, and what is computed for them then is never stored)
+      // (panels j0 < K0 carry both slots)
       constexpr bool two = j0 < K0;
       constexpr int NR = (j0 + 15) / 16;  // registers of a pivot row that hold columns < j0
       double pb[PW][3];
@@ -956,7 +960,7 @@ __device__ __forceinline__ double factor_paired(double *e, int s, int k, int vof
   });
   lexp += __builtin_amdgcn_frexp_exp(lprod);  // (k need not end a panel)
   lprod = __builtin_amdgcn_frexp_mant(lprod);
-  const double zz = -__shfl(dd1, 0, 32);  // row k is slot 1 of lane 0: -dd ends as z'z with z = L^-1 v
+  const double zz = -__shfl(dd1, k - R0, 32);  // row k is the first row of lane k - R0: -dd ends as z'z with z = L^-1 v
   const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
   const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32
   return pd ? ll : NAN;

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
   }
   // ONE copy of the factorisation's straight-line code (4 to 6 thousand instructions).  The first
   // pass's spill is peeled off above, so only the second pass's result registers (56 of the 112) are
-  // live while the first pass factors; with the 60 row entries per lane factor_paired keeps that
+  // live while the first pass factors; with the 48 row entries per lane factor_paired keeps that
   // still fits the register file -- nothing of the epilogue may go to scratch: 100 bytes per lane
   // and block would already double the kernel's HBM traffic
 #ifdef S40_EXP_UNROLLP
