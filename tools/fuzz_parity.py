@@ -1,16 +1,19 @@
 """Randomised parity check of the sweep against the CPU oracle (run on the GPU box): random rank
-1..40, length, sample count and mask fraction; tolerance 1e-8 absolute as in tests/."""
+1..40, length, sample count and mask fraction; tolerance 1e-8 absolute as in tests/.
+    python tools/fuzz_parity.py [trials [kmin [kmax [seed [nmax]]]]]"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import gp_dla_detection_amd as gp
 from gp_dla_detection_amd import synthetic
 from oracle import oracle
-rng = np.random.default_rng(7)
+args = [int(a) for a in sys.argv[1:]]
+trials, kmin, kmax, seed, nmax = (args + [24, 1, 40, 7, 700][len(args):])[:5]
+rng = np.random.default_rng(seed)
 worst = 0.0
-for trial in range(24):
-    k = int(rng.integers(1, 41))
-    n = int(rng.integers(30, 700))
+for trial in range(trials):
+    k = int(rng.integers(kmin, kmax + 1))
+    n = int(rng.integers(30, nmax))
     S = int(rng.integers(1, 90))
     model = synthetic.make_model(k)
     samples = synthetic.make_samples(S)
