@@ -821,16 +821,22 @@ __device__ __forceinline__ double factor_rows(double *e, int s, int k, int voff,
 // instruction (tools/dpp_f64_probe.hip).  p must not have been written by a VALU instruction in
 // the two instructions before (DPP hazard; nothing pads inline assembly): here p always comes
 // straight from an LDS read, and tools/check_dpp_hazard.py checks the ISA of a build.
-template <int N>
+template <int N, bool PAD = false>
 __device__ __forceinline__ void fmac_bcast(double &t, double p, double r) {
-  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(p), "v"(r), "n"(N));
+  if constexpr (PAD)  // p may have been written by the instruction before: two wait states by hand
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(p), "v"(r), "n"(N));
+  else
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(p), "v"(r), "n"(N));
 }
 
 // p[lane N of this lane's 16-lane row] (same hazard rule)
-template <int N>
+template <int N, bool PAD = false>
 __device__ __forceinline__ double mov_bcast(double p) {
   double d;
-  asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(p), "n"(N));
+  if constexpr (PAD)
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(p), "n"(N));
+  else
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(p), "n"(N));
   return d;
 }
 
@@ -961,6 +967,102 @@ __device__ __forceinline__ double factor_paired(double *e, int s, int k, int vof
   lexp += __builtin_amdgcn_frexp_exp(lprod);  // (k need not end a panel)
   lprod = __builtin_amdgcn_frexp_mant(lprod);
   const double zz = -__shfl(dd1, k - R0, 32);  // row k is the first row of lane k - R0: -dd ends as z'z with z = L^-1 v
+  const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
+  const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32
+  return pd ? ll : NAN;
+}
+
+// The factorisation of the 20 < k <= 40 classes with NOTHING in LDS: one sample on the 16 lanes of
+// one DPP row, all its k + 1 rows in registers.  Lane l owns rows l (l < RA = KMAX - 31 = 9), RA + l
+// and RA + 16 + l -- three slots whose rows need 8, 24 and 40 columns: 72 entries per lane.  Every
+// row a column step needs from another lane -- the pivot row's entries, the pivot itself -- lives
+// in a register of the SAME 16-lane row, so the DPP broadcast takes it straight from its owner's
+// register (fmac_bcast / mov_bcast with the owner's lane as a compile-time field): no LDS traffic,
+// no masked stores, no panels, and a slot's multiply-adds stop once its rows are finished
+// (1084 per column sweep at k = 40 for FOUR samples per wave; factor_paired: 808 for two).  A
+// block's 32 samples therefore factor in ONE round, four per wave; LDS only transposes the
+// accumulators into rows (load_rows16 reads what the spill laid down, 16 samples at a time).
+// Entry by entry the operations and their order are those of factor_lds: bit-identical results.
+template <int KMAX> struct Rows16 {
+  static constexpr int RA = KMAX + 1 - 32;
+  static constexpr int NA = RA - 1, NB = RA + 15, NC = KMAX;  // columns the rows of a slot need
+  static_assert(RA >= 2 && RA <= 16, "three slots of at most 16 rows");
+  double a[NA], b[NB], c[NC];  // entry (row, column m): A before column m, L after
+  double da, db, dc;           // running diagonals dd_i = A_ii + 1 - Sum_{m<j} l_im^2 (row k: -z'z)
+};
+
+// e: the sample's spilled columns (packed lower triangle of B, then v at voff), l = 0..15
+template <int KMAX>
+__device__ __forceinline__ void load_rows16(Rows16<KMAX> &R, const double *e, int l, int k, int voff) {
+  using RR = Rows16<KMAX>;
+  const int ia = l, ib = RR::RA + l, ic = RR::RA + 16 + l;
+  // rows beyond k do not exist and row k is v: both read v's storage (the former compute a copy of
+  // z nobody looks at)
+  const bool fa = l < RR::RA && ia < k, fb = ib < k, fc = ic < k;
+  const int roa = fa ? ia * (ia + 1) / 2 : voff, rob = fb ? ib * (ib + 1) / 2 : voff, roc = fc ? ic * (ic + 1) / 2 : voff;
+  R.da = fa ? e[roa + ia] + 1.0 : 0.0;  // log_mvnpdf_low_rank.m:22-23
+  R.db = fb ? e[rob + ib] + 1.0 : 0.0;
+  R.dc = fc ? e[roc + ic] + 1.0 : 0.0;
+#pragma unroll
+  for (int m = 0; m < RR::NA; ++m) R.a[m] = e[roa + m];
+#pragma unroll
+  for (int m = 0; m < RR::NB; ++m) R.b[m] = e[rob + m];
+#pragma unroll
+  for (int m = 0; m < RR::NC; ++m) R.c[m] = e[roc + m];  // (columns >= the row index: unused)
+}
+
+// Returns log N(y; a mu, ...) of the sample (log_mvnpdf_low_rank.m:30-32) in each of its 16 lanes.
+template <int KMAX>
+__device__ __forceinline__ double factor_rows16(Rows16<KMAX> &R, int k, double q_s, double ld_s, int n_kept) {
+  using RR = Rows16<KMAX>;
+  double lprod = 1.0;
+  int lexp = 0;
+  bool pd = true;
+  static_for<KMAX>([&](auto J_) __attribute__((always_inline)) {
+    constexpr int j = decltype(J_)::value;
+    if (j < k) {  // block-uniform
+      constexpr int slot = j < RR::RA ? 0 : j < RR::RA + 16 ? 1 : 2;         // where row j lives ...
+      constexpr int ol = j - (slot == 0 ? 0 : slot == 1 ? RR::RA : RR::RA + 16);  // ... and in which lane
+      constexpr bool act_a = j < RR::NA, act_b = j < RR::NB;  // some row of the slot is still below row j
+      static_for<j>([&](auto M_) __attribute__((always_inline)) {
+        constexpr int mm = decltype(M_)::value;
+        constexpr bool fresh = mm == j - 1;  // the pivot row's newest entry was scaled one column step ago
+        double piv;
+        if constexpr (slot == 0) piv = R.a[mm];
+        else if constexpr (slot == 1) piv = R.b[mm];
+        else piv = R.c[mm];
+        if constexpr (act_a) fmac_bcast<ol, fresh>(R.a[j], piv, R.a[mm]);
+        if constexpr (act_b) fmac_bcast<ol, fresh>(R.b[j], piv, R.b[mm]);
+        fmac_bcast<ol, fresh>(R.c[j], piv, R.c[mm]);
+      });
+      double dsel;
+      if constexpr (slot == 0) dsel = R.da;
+      else if constexpr (slot == 1) dsel = R.db;
+      else dsel = R.dc;
+      const double dj = mov_bcast<ol, true>(dsel);     // pivot
+      pd = pd && (dj > 0.0);                           // chol would throw here (:24)
+      const double inv = rsqrt_nr(dj);
+      lprod *= dj;                                     // 2 Sum log L_jj = log Prod d_j (:30)
+      if constexpr ((j & 3) == 3) {  // (scaling by powers of two is exact: every fourth column gives the same bits)
+        lexp += __builtin_amdgcn_frexp_exp(lprod);
+        lprod = __builtin_amdgcn_frexp_mant(lprod);
+      }
+      if constexpr (act_a) {
+        R.a[j] *= inv;
+        R.da = fma(-R.a[j], R.a[j], R.da);             // (a finished row's dd is dead)
+      }
+      if constexpr (act_b) {
+        R.b[j] *= inv;
+        R.db = fma(-R.b[j], R.b[j], R.db);
+      }
+      R.c[j] *= inv;
+      R.dc = fma(-R.c[j], R.c[j], R.dc);
+    }
+  });
+  lexp += __builtin_amdgcn_frexp_exp(lprod);  // (k need not be a multiple of four)
+  lprod = __builtin_amdgcn_frexp_mant(lprod);
+  // row k: -dd ends as z'z with z = L^-1 v
+  const double zz = -(k >= RR::RA + 16 ? __shfl(R.dc, k - RR::RA - 16, 16) : __shfl(R.db, k - RR::RA, 16));
   const double log_det = ld_s + log(lprod) + (double)lexp * 0.6931471805599453;  // :30
   const double ll = -0.5 * ((q_s - zz) + log_det + (double)n_kept * kLog2Pi);    // :32
   return pd ? ll : NAN;

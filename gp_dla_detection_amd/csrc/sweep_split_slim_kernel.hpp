@@ -29,9 +29,14 @@
 //     one iteration ahead of stage C, stage R 20 raw steps ahead (a ring of 128 slots per sample).
 //     The multi-DLA form gathers profile values in place of stage R.
 //
+//   * Epilogue.  The 32 Cholesky factorisations of a block run in registers, one sample per 16-lane
+//     DPP row, four per wave, in one round (factor_rows16, sweep_kernels.hpp); LDS only transposes
+//     the accumulators into rows.
+//
 // Results are bit-identical to the pre-expanded kernels': the same products, the same MFMA sequence
-// per column, the same epilogue.  (S40_EXP_*: ablation switches of diagnostic builds, tools/ab_build.sh;
-// their results are wrong by construction.)
+// per column, the same operations in the epilogue.  (S40_EXP_*: ablation and A/B switches of
+// diagnostic builds, tools/ab_build.sh; NO* results are wrong by construction, S40_EXP_PAIRED and
+// S40_EXP_LDSEPI select this round's earlier epilogues.)
 #pragma once
 #include <type_traits>
 
@@ -39,7 +44,7 @@
 #include "sweep_split_kernel.hpp"
 
 #ifndef S40_EPI_PW
-#define S40_EPI_PW 4  // columns per panel of the epilogue's factorisation (factor_paired)
+#define S40_EPI_PW 4  // columns per panel of factor_paired (-DS40_EXP_PAIRED)
 #endif
 
 namespace gpdla {
@@ -488,8 +493,7 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
   __syncthreads();  // red is read; the epilogue may now overwrite everything behind the exp table
 
   // ---- epilogue: every wave spills result registers 2p, 2p + 1 of its 7 tiles, for both groups, to
-  // the groups' LDS rows (row rho = 2 jj + h holds sample jj + 4 (2p + h)) through the column map;
-  // wave (g, r) then factors rows 2r and 2r + 1 of group g, 32 lanes per sample (as k_sweep_split).
+  // the groups' LDS rows (row rho = 2 jj + h holds sample jj + 4 (2p + h)) through the column map
   using ES = EpilogueShape<TW, 4>;
   constexpr int ncols = ES::stride(logical_tiles(NT));
   constexpr int voff = TW * 16;
@@ -498,6 +502,57 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
   for (int cc = 0; cc < NTW; ++cc) at[cc] = s40_pos(wave_s * NTW + cc, s);
   double *Eg = stage;
   double *e0 = Eg + (size_t)(jj * 2) * ncols, *e1 = e0 + (size_t)ES::SPP * ncols;
+#if !defined(S40_EXP_LDSEPI) && !defined(S40_EXP_PAIRED) && !defined(S40_EXP_NOEPI)
+  // The accumulators pass through LDS in two rounds of 16 samples (32 x 861 doubles do not fit) only
+  // to be transposed into rows: after round p the waves of roles 2p, 2p + 1 take four of its samples
+  // each -- one per 16-lane row, all k + 1 rows of a sample in registers (load_rows16) -- and once
+  // both rounds are through, all eight waves factor their four samples at once, in registers
+  // (factor_rows16).  The waves keep to samples of their own group: its scalar sums are in their lanes.
+  Rows16<40> R;
+  const int round_mine = role >> 1;
+  const int rho = 4 * (role & 1) + jj;  // the group's LDS row this 16-lane row takes
+  {
+    const double *erow = Eg + (size_t)(group * ES::SPP + rho) * ncols;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      __syncthreads();  // p = 0: the loop's buffers are dead; p = 1: round 0's rows are in registers
+#pragma unroll
+      for (int cc = 0; cc < NTW; ++cc) {
+        e0[at[cc]] = acc0[cc][2 * p];
+        e0[ncols + at[cc]] = acc0[cc][2 * p + 1];
+        e1[at[cc]] = acc1[cc][2 * p];
+        e1[ncols + at[cc]] = acc1[cc][2 * p + 1];
+      }
+      __syncthreads();
+      if (round_mine == p) load_rows16<40>(R, erow, s, a.k, voff);  // wave-uniform
+    }
+  }
+  {
+    const int p = round_mine;
+    const int sigma = (rho >> 1) + 4 * (2 * p + (rho & 1));  // Mat<double>::sample_of(jj, reg)
+    const double q_s = __shfl(quad_sum, sigma), ld_s = __shfl(logd_sum, sigma);
+    const double ll = factor_rows16<40>(R, a.k, q_s, ld_s, m.n_kept);
+    const bool writer_lane = s == 0;
+    const int64_t slot_s = slot0 + sigma;
+    if constexpr (kMulti) {
+      const bool ok_s = __shfl(chain_ok, sigma) != 0;
+      if (writer_lane) {
+        if (slot_s < a.S) {
+          if (a.mode == 0) a.sample_ll_lls[q * a.S + slot_s] = ll + m.ll_bias - a.log_S;     // multi :376-378
+          else a.sample_ll_dla[(q * a.max_dlas + (a.mode - 1)) * a.S + slot_s] = ok_s ? ll + m.ll_bias - a.log_S : NAN;  // :359-361
+        } else if (slot_s == a.S && a.mode == 1) {
+          a.ll_no_dla[q] = ll + m.ll_bias;                                                    // multi :296-298
+        }
+      }
+    } else {
+      const int32_t sample_s = __shfl(sample, sigma);
+      if (writer_lane) {
+        if (slot_s < a.S) a.sample_ll[(int64_t)q * a.S + sample_s] = ll + m.ll_bias;
+        else if (slot_s == a.S) a.ll_no_dla[q] = ll + m.ll_bias;
+      }
+    }
+  }
+#else  // the round-4 predecessors, for A/B: two passes of 16 samples, 32 lanes per sample, factored next to LDS
   __syncthreads();  // the loop's buffers are dead
 #pragma unroll
   for (int cc = 0; cc < NTW; ++cc) {
@@ -559,6 +614,7 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
       }
     }
   }
+#endif
 }
 
 }  // namespace gpdla
