@@ -9,7 +9,10 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for group in "SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+# (FETCH_SIZE and WRITE_SIZE each in a pass of their own: derived TCC counters, in KiB per launch;
+# FETCH_SIZE is doubled for gfx950 by whoever reads the sums, as in tools/pmc_to_json.py)
+for group in "FETCH_SIZE" "WRITE_SIZE" \
+             "SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"; do
   name=$(echo $group | tr ' ' '_' | cut -c1-40)
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $group --output-format csv -d $OUT/pmcm_${TAG}_$name -- \
