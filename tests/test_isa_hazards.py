@@ -47,3 +47,12 @@ def test_shipped_kernels_have_no_dpp_hazard(tmp_path, capsys):
     assert text.count("v_fmac_f64_dpp") > 1000 and "v_mov_b64_dpp" in text  # (the check below is not vacuous)
     assert _checker().main(dumps[0]) == 0, capsys.readouterr().out
     capsys.readouterr()
+    # ... and none of the sweep kernels may start keeping things in scratch: a private array of 224
+    # bytes per lane in the k <= 40 epilogue once moved 18 GB of HBM traffic per launch (DESIGN.md
+    # section 4); what they have today is a handful of prologue spills
+    import re
+    sizes = {m.group(1): int(m.group(2)) for m in re.finditer(
+        r"\.name:\s+(\S+)\n(?:(?!\.name:).)*?\.private_segment_fixed_size:\s+(\d+)", text, re.S)}
+    sweeps = {k: v for k, v in sizes.items() if "k_sweep" in k}
+    assert len(sweeps) >= 10, sorted(sizes)
+    assert max(sweeps.values()) <= 64, {k: v for k, v in sweeps.items() if v > 64}
