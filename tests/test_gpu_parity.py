@@ -235,10 +235,12 @@ def test_rank_40_model(oracle):
     assert np.abs(out["sample_log_likelihoods_dla"][0] - ref["sample_log_likelihoods_dla"]).max() < TOL
 
 
-@pytest.mark.parametrize("k", [21, 27, 33])
+@pytest.mark.parametrize("k", [21, 24, 25, 27, 33, 39])
 def test_ranks_between_the_tile_classes(oracle, k):
     """20 < k < 40 runs on the k <= 40 kernel with zero-padded tiles: 21 is the first rank past the
-    one-wave class, 27 and 33 leave different numbers of the 52 + 4 tiles (partly) empty."""
+    one-wave class, 27 and 33 leave different numbers of the 52 + 4 tiles (partly) empty.  The
+    epilogue deals rows 0..8 / 9..24 / 25..40 to three register slots (factor_rows16): at k = 24 the
+    last row (v) is the last of the second slot, at k = 25 the first of the third."""
     model = synthetic.make_model(k)
     samples = synthetic.make_samples(40)
     sp = synthetic.make_spectrum(52 + k, 333, model, mask_fraction=0.03)
