@@ -1142,6 +1142,15 @@ __device__ __forceinline__ double factor_pass(const ACC (&acc)[NTW], const doubl
   if (role != 0) return NAN;
   if (TW <= 14)  // k <= 20: own rows in registers
     return factor_rows<ES::ROWS, ES::LPS, 20>(e + half * ncols, s & (ES::LPS - 1), k, voff, q_s, ld_s, n_kept);
+#ifndef GPDLA_EXP_LDSEPI
+  if constexpr (TW > 30 && ES::LPS == 16) {
+    // k <= 40 without a tile split (the fp32 study kernel): a sample is on the 16 lanes of one DPP
+    // row already -- all its rows in registers, nothing read from LDS after the spill (factor_rows16)
+    Rows16<40> R;
+    load_rows16<40>(R, e, s, k, voff);
+    return factor_rows16<40>(R, k, q_s, ld_s, n_kept);
+  }
+#endif
   return factor_lds<ES::ROWS, ES::LPS>(e + half * ncols, s & (ES::LPS - 1), k, voff, q_s, ld_s, n_kept);
 #endif
 }
