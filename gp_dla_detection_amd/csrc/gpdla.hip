@@ -1786,7 +1786,16 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   fa.nlogp = t->d_nlogp;
   fa.not_pd = t->d_flag;
   fa.group_stride = strideD;
-  hipLaunchKernelGGL(k_train_factor<KMAX>, dim3((unsigned)((d.NQ16 * 16 + TrF<KMAX>::FQ - 1) / TrF<KMAX>::FQ)), dim3(256), 0, st, fa);
+  // k <= 40: the per-quasar algebra in registers (k_train_factor16); GPDLA_TRAIN_FACTOR_LDS=1 (diagnostic): the
+  // round-3 kernel, which stays the k <= 20 form
+  static const bool factor_lds = std::getenv("GPDLA_TRAIN_FACTOR_LDS") != nullptr;
+  const dim3 factor_grid((unsigned)((d.NQ16 * 16 + TrF<KMAX>::FQ - 1) / TrF<KMAX>::FQ));
+  if constexpr (KMAX == 40) {
+    if (factor_lds) hipLaunchKernelGGL(k_train_factor<KMAX>, factor_grid, dim3(256), 0, st, fa);
+    else hipLaunchKernelGGL(k_train_factor16<KMAX>, factor_grid, dim3(kTrF16Threads), 0, st, fa);
+  } else {
+    hipLaunchKernelGGL(k_train_factor<KMAX>, factor_grid, dim3(256), 0, st, fa);
+  }
   TrainCoreArgs co;
   co.d = d;
   co.recP = t->d_recP;

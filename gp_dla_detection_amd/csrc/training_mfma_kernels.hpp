@@ -757,6 +757,354 @@ __global__ __launch_bounds__(256, 2) void k_train_factor(TrainFactorArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_train_factor16 (k <= 40): the per-quasar algebra of k_train_factor in registers.
+// k_train_factor keeps a quasar on 40 lanes and reads L, L^-1 and the column exchange of the
+// Cholesky as broadcast LDS reads -- ~1250 of them per quasar, the pattern that bounds the old sweep
+// epilogues (48 cycles per instruction with eight waves per CU, tools/dpp_f64_probe.hip).  Here a
+// quasar sits on the 16 lanes of ONE DPP row, four quasars per wave, rows dealt as in Rows16
+// (sweep_kernels.hpp: lane l owns rows l < 9, 9 + l and 25 + l; row 40 is t), and every cross-lane
+// operand is a register of the same row, broadcast by v_fmac_f64_dpp:
+//   Cholesky      left-looking, the pivot row's entries from their owner (as factor_rows16); the
+//                 augmented row t comes out as y = L^-1 t, its running diagonal as -y'y = -t'z
+//   L^-1          lane(a) solves L x = e_a for its rows a (the COLUMNS a of L^-1 = rows of U = L^-T):
+//                 row r of L is broadcast from its owner, x stays in the lane; one slot at a time, so
+//                 that L (72 entries per lane) and the columns built so far (40 + 31 + 15) fit
+//   z = L^-T y    z_a = Sum_r U_a[r] y_r, y broadcast from the lane that owns row 40
+//   B^-1 = U U'   entry (a, c) = Sum_r U_a[r] U_c[r]: row c of U broadcast from its owner; the entry
+//                 goes straight to vech(B^-1) in s_S
+// Ranks below 40 are padded with identity rows (read from the zero columns behind t), so the code has
+// no rank-dependent branch.  The operation order differs from k_train_factor's (left- instead of
+// right-looking, other summation orders): results agree to rounding, not bit for bit.
+// ------------------------------------------------------------------------------------------
+template <int KMAX>
+__device__ __forceinline__ void train_factor16(double *sS, double *sz, int l, int k, double *tz_out,
+                                               double *two_ld_out, bool *pd_out) {
+  using RR = Rows16<KMAX>;
+  constexpr int RA = RR::RA, RB = RA + 16;           // first rows of the second and third slot: 9, 25
+  constexpr int voff = TrK<KMAX>::W * 16;            // t behind the vech columns
+  constexpr int zoff = voff + 16 * TrK<KMAX>::U;     // the pad of zeros behind t (k_train_factor16 lays it down)
+  static_assert(KMAX == 40 && RA == 9, "three slots: rows 0..8, 9..24, 25..40");
+  const int ia = l, ib = RA + l, ic = RB + l;        // ic == KMAX: the row of t
+  const bool fa = l < RA && ia < k, fb = ib < k, fc = ic < k, ft = ic == KMAX;
+  const int roa = fa ? ia * (ia + 1) / 2 : zoff, rob = fb ? ib * (ib + 1) / 2 : zoff;
+  const int roc = fc ? ic * (ic + 1) / 2 : ft ? voff : zoff;
+  Rows16<KMAX> R;
+  R.da = (fa ? sS[roa + ia] : 0.0) + 1.0;            // B = I + Sum (spectrum_loss.m:34-42); identity rows: 1
+  R.db = (fb ? sS[rob + ib] : 0.0) + 1.0;
+  R.dc = ft ? 0.0 : (fc ? sS[roc + ic] : 0.0) + 1.0;
+#pragma unroll
+  for (int m = 0; m < RR::NA; ++m) R.a[m] = sS[roa + m];
+#pragma unroll
+  for (int m = 0; m < RR::NB; ++m) R.b[m] = sS[rob + m];
+#pragma unroll
+  for (int m = 0; m < RR::NC; ++m) R.c[m] = sS[roc + m];  // (columns >= the row index: unused)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // every lane has its rows: vech(B^-1) may overwrite s_S from here on
+
+  // ---- Cholesky (spectrum_loss.m:42), all KMAX columns; 1 / L_jj kept by the owner of row j
+  double lprod = 1.0, inva = 1.0, invb = 1.0, invc = 1.0;
+  int lexp = 0;
+  bool pd = true;
+  static_for<KMAX>([&](auto J_) __attribute__((always_inline)) {
+    constexpr int j = decltype(J_)::value;
+    constexpr int slot = j < RA ? 0 : j < RB ? 1 : 2;
+    constexpr int ol = j - (slot == 0 ? 0 : slot == 1 ? RA : RB);
+    constexpr bool act_a = j < RR::NA, act_b = j < RR::NB;
+    static_for<j>([&](auto M_) __attribute__((always_inline)) {
+      constexpr int mm = decltype(M_)::value;
+      constexpr bool fresh = mm == j - 1;
+      double piv;
+      if constexpr (slot == 0) piv = R.a[mm];
+      else if constexpr (slot == 1) piv = R.b[mm];
+      else piv = R.c[mm];
+      if constexpr (act_a) fmac_bcast<ol, fresh>(R.a[j], piv, R.a[mm]);
+      if constexpr (act_b) fmac_bcast<ol, fresh>(R.b[j], piv, R.b[mm]);
+      fmac_bcast<ol, fresh>(R.c[j], piv, R.c[mm]);
+    });
+    double dsel;
+    if constexpr (slot == 0) dsel = R.da;
+    else if constexpr (slot == 1) dsel = R.db;
+    else dsel = R.dc;
+    const double dj = mov_bcast<ol, true>(dsel);
+    pd = pd && (dj > 0.0);
+    const double inv = rsqrt_nr(dj);  // 1 / L_jj
+    lprod *= dj;                      // 2 Sum log L_jj = log Prod d_j
+    if constexpr ((j & 3) == 3) {
+      lexp += __builtin_amdgcn_frexp_exp(lprod);
+      lprod = __builtin_amdgcn_frexp_mant(lprod);
+    }
+    if (l == ol) {  // (a select under a constant lane mask)
+      if constexpr (slot == 0) inva = inv;
+      else if constexpr (slot == 1) invb = inv;
+      else invc = inv;
+    }
+    if constexpr (act_a) {
+      R.a[j] *= inv;
+      R.da = fma(-R.a[j], R.a[j], R.da);
+    }
+    if constexpr (act_b) {
+      R.b[j] *= inv;
+      R.db = fma(-R.b[j], R.b[j], R.db);
+    }
+    R.c[j] *= inv;
+    R.dc = fma(-R.c[j], R.c[j], R.dc);
+  });
+  *tz_out = -mov_bcast<15, true>(R.dc);  // row 40 is the third row of lane 15: -dd ended as y'y = t'z
+  *two_ld_out = log(lprod) + (double)lexp * 0.6931471805599453;
+  *pd_out = pd;
+
+  // ---- columns of L^-1 (rows of U = L^-T), one slot at a time; z = U y on the way
+  // row r of L: register [m] of its owner's slot array; 1 / L_rr: the owner's inv of that slot
+  double xa[KMAX], za = 0.0;
+  static_for<KMAX>([&](auto R_) __attribute__((always_inline)) {
+    constexpr int r = decltype(R_)::value;
+    constexpr int slot = r < RA ? 0 : r < RB ? 1 : 2;
+    constexpr int ol = r - (slot == 0 ? 0 : slot == 1 ? RA : RB);
+    double s = slot == 0 && l == ol ? 1.0 : 0.0;  // delta_ra - Sum_m L_rm x_m (fmac_bcast subtracts the product)
+    static_for<r>([&](auto M_) __attribute__((always_inline)) {
+      constexpr int mm = decltype(M_)::value;
+      double lr;
+      if constexpr (slot == 0) lr = R.a[mm];
+      else if constexpr (slot == 1) lr = R.b[mm];
+      else lr = R.c[mm];
+      fmac_bcast<ol>(s, lr, xa[mm]);
+    });
+    const double invr = mov_bcast<ol, true>(slot == 0 ? inva : slot == 1 ? invb : invc);
+    xa[r] = s * invr;
+    fmac_bcast<15>(za, R.c[r], xa[r]);  // za -= y_r x_a[r]
+  });
+  double xb[KMAX - RA], zb = 0.0;  // x_b[r - RA], r >= RA
+  static_for<KMAX - RA>([&](auto R_) __attribute__((always_inline)) {
+    constexpr int r = RA + decltype(R_)::value;
+    constexpr int slot = r < RB ? 1 : 2;
+    constexpr int ol = r - (slot == 1 ? RA : RB);
+    double s = slot == 1 && l == ol ? 1.0 : 0.0;
+    static_for<r - RA>([&](auto M_) __attribute__((always_inline)) {
+      constexpr int mm = RA + decltype(M_)::value;
+      double lr;
+      if constexpr (slot == 1) lr = R.b[mm];
+      else lr = R.c[mm];
+      fmac_bcast<ol>(s, lr, xb[mm - RA]);
+    });
+    const double invr = mov_bcast<ol, true>(slot == 1 ? invb : invc);
+    xb[r - RA] = s * invr;
+    fmac_bcast<15>(zb, R.c[r], xb[r - RA]);
+  });
+  double xc[KMAX - RB], zc = 0.0;  // x_c[r - RB], r >= RB
+  static_for<KMAX - RB>([&](auto R_) __attribute__((always_inline)) {
+    constexpr int r = RB + decltype(R_)::value;
+    constexpr int ol = r - RB;
+    double s = l == ol ? 1.0 : 0.0;
+    static_for<r - RB>([&](auto M_) __attribute__((always_inline)) {
+      constexpr int mm = RB + decltype(M_)::value;
+      fmac_bcast<ol>(s, R.c[mm], xc[mm - RB]);
+    });
+    const double invr = mov_bcast<ol, true>(invc);
+    xc[r - RB] = s * invr;
+    fmac_bcast<15>(zc, R.c[r], xc[r - RB]);
+  });
+  // z (fmac_bcast accumulated -Sum): rows of t's lane and laneless slots are not stored
+  if (l < RA) sz[ia] = -za;
+  sz[ib] = -zb;
+  if (ic < KMAX) sz[ic] = -zc;
+
+  // ---- B^-1 = U U': entry (a, c), c <= a, = Sum_{r >= a} U_a[r] U_c[r]; row c of U from its owner
+  static_for<KMAX>([&](auto C_) __attribute__((always_inline)) {
+    constexpr int c = decltype(C_)::value;
+    constexpr int slot = c < RA ? 0 : c < RB ? 1 : 2;
+    constexpr int ol = c - (slot == 0 ? 0 : slot == 1 ? RA : RB);
+    constexpr int r0a = c, r0b = c > RA ? c : RA, r0c = c > RB ? c : RB;  // first r with both factors possibly nonzero
+    double acca = 0.0, accb = 0.0, accc = 0.0;
+    static_for<KMAX - r0c>([&](auto R_) __attribute__((always_inline)) {  // the rows every slot sums over
+      constexpr int r = r0c + decltype(R_)::value;
+      double uc;
+      if constexpr (slot == 0) uc = xa[r];
+      else if constexpr (slot == 1) uc = xb[r - RA];
+      else uc = xc[r - RB];
+      if constexpr (slot == 0) fmac_bcast<ol>(acca, uc, xa[r]);
+      if constexpr (slot <= 1) fmac_bcast<ol>(accb, uc, xb[r - RA]);
+      fmac_bcast<ol>(accc, uc, xc[r - RB]);
+    });
+    if constexpr (slot <= 1) {  // rows r0b .. r0c - 1: the third slot's columns have not started there
+      static_for<r0c - r0b>([&](auto R_) __attribute__((always_inline)) {
+        constexpr int r = r0b + decltype(R_)::value;
+        double uc;
+        if constexpr (slot == 0) uc = xa[r];
+        else uc = xb[r - RA];
+        if constexpr (slot == 0) fmac_bcast<ol>(acca, uc, xa[r]);
+        fmac_bcast<ol>(accb, uc, xb[r - RA]);
+      });
+    }
+    if constexpr (slot == 0) {  // rows r0a .. r0b - 1: the first slot's columns only
+      static_for<r0b - r0a>([&](auto R_) __attribute__((always_inline)) {
+        constexpr int r = r0a + decltype(R_)::value;
+        fmac_bcast<ol>(acca, xa[r], xa[r]);
+      });
+    }
+    int cc = c;  // (opaque: or all compares are formed up front)
+    asm volatile("" : "+s"(cc));
+    if constexpr (slot == 0)
+      if (l < RA && ia >= cc) sS[ia * (ia + 1) / 2 + c] = -acca;
+    if constexpr (slot <= 1)
+      if (ib >= cc) sS[ib * (ib + 1) / 2 + c] = -accb;
+    if (ic >= cc && ic < KMAX) sS[ic * (ic + 1) / 2 + c] = -accc;
+  });
+}
+
+constexpr int kTrF16Threads = 64;  // ONE wave per block: it loads, factors and stores its four quasars
+template <int KMAX>
+__global__ __launch_bounds__(kTrF16Threads) void k_train_factor16(TrainFactorArgs a) {
+  // The shell of k_train_factor (partial sums in, the two operand tilings out) around train_factor16.
+  // A block is one wave and four quasars, one per 16-lane row.  LDS is the summed row of a quasar --
+  // its used columns and a pad of zeros -- and nothing else (k_train_factor keeps L / L^-1 there
+  // too, stages the recE rows over them and idles three of its four waves while one factors): five
+  // blocks per CU, 5120 quasars in flight on the chip.
+  using K = TrC<KMAX>;
+  constexpr int FQ = 4, NT = kTrF16Threads;
+  constexpr int Used = K::W * 16 + 16 * K::U;  // columns that can be non-zero: vech, then t (880)
+  constexpr int Row = Used + 48;               // ... and zeros behind them (train_factor16 reads identity rows there)
+  static_assert(TrF<KMAX>::FQ == FQ, "the grid and the recD steps of k_train_factor");
+  static_assert(Row - Used >= KMAX, "identity rows read KMAX zeros behind the used columns");
+  __shared__ __attribute__((aligned(16))) double s_S[FQ][Row];
+  __shared__ __attribute__((aligned(16))) double s_z[FQ][KMAX];
+  __shared__ double s_sc[FQ][4];
+  __shared__ int s_good[FQ];
+  __shared__ uint8_t s_vi[K::W * 16], s_vj[K::W * 16];
+  static_assert(4 * K::KsW <= 16 * K::W && 4 * K::KsU <= 16 * K::U, "recE columns are a prefix of recD's");
+  const TrainDims &D = a.d;
+  const int tid = threadIdx.x, k = D.k;
+  const int64_t q0 = (int64_t)blockIdx.x * FQ, nq_pad = D.NQ16 * 16;
+  const int nb = k * (k + 1) / 2;
+  {  // (i, j) of vech column c: one square root per lane, then 64 columns further at a time
+    int i = 0, j = 0;
+    vech_ij(tid, &i, &j);
+    for (int c = tid; c < K::W * 16; c += NT) {
+      s_vi[c] = (uint8_t)(c < nb ? i : 0);
+      s_vj[c] = (uint8_t)(c < nb ? j : 0);
+      j += NT;
+      while (j > i) {
+        j -= i + 1;
+        ++i;
+      }
+    }
+  }
+  // [vech(B - I) | t] = Sum_h partial, in split order; lanes along the columns (coalesced), seven
+  // columns of a lane at a time so that 28 loads are in flight (the loop is latency-bound); only the
+  // columns that can be non-zero are read, the pad behind them is laid down here
+  static_assert(Used <= 14 * NT, "two halves of seven columns per lane");
+#pragma unroll 1
+  for (int ql = 0; ql < FQ; ++ql) {
+    const int64_t q = q0 + ql;
+    const bool onq = q < D.nq;
+    const double *base = a.partB + (((onq ? q >> 4 : 0) * D.H) * 16 + (onq ? q & 15 : 0)) * (int64_t)K::Cols + tid;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double v[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int h0 = 0; h0 < D.H; h0 += 4) {
+        double pv[7][4];
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+#pragma unroll
+          for (int hh = 0; hh < 4; ++hh) {
+#ifdef TF16_EXP_NOLOAD  // ablation: no partial sums read (results wrong by construction)
+            pv[u][hh] = 1e-6 * (u + hh);
+#else
+            const bool on = onq && tid + NT * (7 * half + u) < Used && h0 + hh < D.H;
+            pv[u][hh] = on ? base[NT * (7 * half + u) + (int64_t)(h0 + hh) * 16 * K::Cols] : 0.0;
+#endif
+          }
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+#pragma unroll
+          for (int hh = 0; hh < 4; ++hh)
+            if (h0 + hh < D.H) v[u] += pv[u][hh];  // (added in split order)
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int c = tid + NT * (7 * half + u);
+        if (c < Row) s_S[ql][c] = c < Used ? v[u] : 0.0;
+      }
+    }
+    if (14 * NT < Row && tid + 14 * NT < Row) s_S[ql][tid + 14 * NT] = 0.0;
+  }
+  for (int e = tid; e < FQ * 3; e += NT) {
+    const int ql = e / 3, which = e % 3;
+    const int64_t q = q0 + ql;
+    double v = 0.0;
+    if (q < D.nq)
+      for (int b = 0; b < D.H; ++b) v += a.part1[(q * D.H + b) * 3 + which];
+    s_sc[ql][which] = v;
+  }
+  __syncthreads();
+  {
+    const int ql = tid >> 4, l = tid & 15;
+    const int64_t q = q0 + ql;
+    const bool real = q < D.nq;
+    double tz, two_ld;
+    bool pd;
+#ifdef TF16_EXP_NOFACTOR  // ablation: no factorisation (results wrong by construction)
+    tz = s_S[ql][l];
+    two_ld = 0.0;
+    pd = true;
+    if (l < 8) s_z[ql][l] = tz;
+#else
+    train_factor16<KMAX>(s_S[ql], s_z[ql], l, k, &tz, &two_ld, &pd);
+#endif
+    if (l == 0) {
+      const double log_2pi = 1.83787706640934534;  // spectrum_loss.m:17
+      const double v = 0.5 * ((s_sc[ql][1] - tz) + s_sc[ql][0] + two_ld + s_sc[ql][2] * log_2pi);  // :48-52
+      const bool good = real && pd && v == v;  // (NaN: a pivot, or a variance d, that was not positive)
+      if (real && !good) *a.not_pd = 1;
+      s_good[ql] = good ? 1 : 0;
+      if (q < nq_pad) a.nlogp[q] = good ? v : 0.0;  // (nlogp is allocated for the padded quasar count)
+    }
+  }
+  __syncthreads();
+  // T = B^-1 + z z' (zero for padded / failed quasars) in place in s_S: the recD rows
+  // (one wave does the work four did in k_train_factor: the loops of the shell are unrolled so that
+  // their LDS reads and stores are in flight together)
+#pragma unroll 5
+  for (int e = tid; e < FQ * Used; e += NT) {
+    const int qe = e / Used, c = e % Used;
+    const bool good = s_good[qe] != 0;
+    double v = 0.0;
+    if (c < K::W * 16) {
+      if (good && c < nb) v = s_S[qe][c] + s_z[qe][s_vi[c]] * s_z[qe][s_vj[c]];
+    } else {
+      const int cz = c - K::W * 16;
+      if (good && cz < k) v = s_z[qe][cz];
+    }
+    s_S[qe][c] = v;
+  }
+  __syncthreads();
+  // recD: [group][tq][16 tiles][jj = quasar % 4][col]: the block's four quasars are one quasar step
+  // (the tiles behind the used columns are padding: recD is zeroed when it is allocated and nobody
+  // ever writes anything but zeros there)
+  static_assert(Used % 16 == 0, "whole tiles of used columns");
+#pragma unroll 5
+  for (int e = tid; e < (Used / 16) * 64; e += NT) {
+    const int c = e >> 6, jj = (e >> 4) & 3, col = e & 15;
+    const int64_t tq = q0 >> 2;
+    if (tq < D.TQ) a.recD[(c >> 4) * a.group_stride + (tq * 16 + (c & 15)) * 64 + (e & 63)] = s_S[jj][16 * c + col];
+  }
+  // recE: [g][Ks][jj = column % 4][s = quasar % 16], off-diagonals doubled (m'T m = Sum_{i>=j} (2 - delta_ij)
+  // T_ij m_i m_j): its columns are a prefix of the vech columns, then of z
+#pragma unroll 6
+  for (int e = tid; e < K::Ks * 4 * FQ; e += NT) {
+    const int qe = e % FQ, kj = e / FQ;  // kj = 4 ks + jj
+    const int64_t qq = q0 + qe;
+    double v;
+    if (kj < 4 * K::KsW) {
+      v = s_S[qe][kj];
+      if (s_vi[kj] != s_vj[kj]) v *= 2.0;
+    } else {
+      v = s_S[qe][K::W * 16 + (kj - 4 * K::KsW)];
+    }
+    if (qq < nq_pad) a.recE[(qq >> 4) * K::Ks * 64 + (int64_t)kj * 16 + (qq & 15)] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_train_core: one wave per (pixel group pt, split gs of the quasar groups).
 // X_qp = m_p' T_q m_p (KsW column steps), Y_qp = m_p' z_q (KsU column steps) by MFMA, then
 // core_qp and the sums over the wave's quasars: partcol[pt][gs][16] = Sum an core per pixel,
