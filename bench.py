@@ -180,6 +180,44 @@ def cpu_baseline(model, samples, spectra, seconds_target=6.0, repeats=3):
                        f"single_core_value from {one_count} samples on 1 thread (best of 3)")
 
 
+def pcie_c_leg(model, samples, spectra, lp, params, device, S, resident_rate, n_pc=2048, repeats=3):
+    """gpdla_process_batch -- host CSR arrays in, host result arrays out, everything between inside the
+    library (its own upload / sweep / download threads) -- called through ctypes the way a C or MEX
+    consumer calls it: ONE call for n_pc quasars, default batching.  The arrays are built before the
+    clock starts (a caller has them: preloaded_qsos.mat); the result arrays are fresh (untouched pages)
+    for every repeat, as a caller's would be.  Median of `repeats`."""
+    import ctypes as C
+
+    import gp_dla_detection_amd as gp
+    from gp_dla_detection_amd import _lib, api
+    lib = _lib.load()
+    many = [spectra[i % len(spectra)] for i in range(n_pc)]
+    csr = api.spectra_to_csr(many)
+    lp_no, lp_dla = np.resize(lp[0], n_pc), np.resize(lp[1], n_pc)
+    cfg = api._config(params)
+    keep = []
+    m, s_ = api._model_struct(model, keep), api._samples_struct(samples, keep)
+    sp = api._spectra_struct(csr, lp_no, lp_dla, None, keep)
+    small = api.process_qsos(model, samples, many[:64], log_priors=(lp_no[:64], lp_dla[:64]), device=device,
+                             params=params)  # warm-up of the host paths (and a reference for the check below)
+    times = []
+    for _ in range(repeats):
+        out = gp.Batch.empty_results(n_pc, S, True)
+        r = api._result_struct(_lib.Results, out)
+        t0 = time.perf_counter()
+        _lib.check(lib.gpdla_process_batch(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r), int(device)))
+        times.append(time.perf_counter() - t0)
+    np.testing.assert_array_equal(out["sample_log_likelihoods_dla"][:64], small["sample_log_likelihoods_dla"])
+    assert not np.isnan(out["log_likelihoods_dla"]).any()
+    dt = float(np.median(times))
+    rate = n_pc * S / dt
+    return {"what": f"gpdla_process_batch through ctypes: {n_pc} quasars as CSR host arrays in, "
+                    f"{out['sample_log_likelihoods_dla'].nbytes / 1e6:.0f} MB of results out, one call (upload / sweep / "
+                    "download pipelined inside the library); never `value`",
+            "evals_per_s": rate, "seconds": times, "over_resident": rate / resident_rate,
+            "batch_quasars": api.default_batch_size(n_pc, int(np.diff(csr["offsets"]).max()), int(m.k), S, 3)}
+
+
 def self_launch(n: int, argv) -> int:
     """`python bench.py --gpus N` typed directly (no WORLD_SIZE in the environment): run the N
     ranks as child processes of this one, which has made no GPU call and makes none -- a process
@@ -275,6 +313,9 @@ def main():
     ap.add_argument("--pcie", action="store_true",
                     help="also time the one-shot host-buffer entry point (H2D + sweep + D2H); "
                          "reported as config.pcie_inclusive_evals_per_s, never as value")
+    ap.add_argument("--pcie-c", action="store_true",
+                    help="also time gpdla_process_batch itself -- the one-shot C entry a MEX gateway binds -- on 2048 "
+                         "quasars handed over as CSR host arrays through ctypes (config.pcie_c, never value)")
     ap.add_argument("--timeout-min", type=float, default=10.0, help="process-group timeout (N > 1)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -512,6 +553,8 @@ def main():
                                                       f"{res_pc['sample_log_likelihoods_dla'].nbytes / 1e6:.0f} MB of "
                                                       "results out; upload / sweep / download pipelined)")
             out["config"]["pcie_inclusive_over_resident"] = out["config"]["pcie_inclusive_evals_per_s"] / value
+        if args.pcie_c and world == 1:
+            out["config"]["pcie_c"] = pcie_c_leg(model, samples, spectra, lp, params, local_rank, args.samples, value)
         if (world == 1 and args.workload == "configs1" and args.contraction == "f64" and args.k <= 20
                 and not args.no_mix_rider):
             # the production shape beside the headline: ONE launch of 1000 quasars of the DR12Q length

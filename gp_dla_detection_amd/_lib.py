@@ -66,7 +66,8 @@ class Config(C.Structure):
                 ("min_z_separation", C.c_double), ("prev_tau_0", C.c_double),
                 ("prev_beta", C.c_double), ("rng_seed", C.c_uint64),
                 ("first_quasar_index", C.c_int64), ("contraction_precision", C.c_int32),
-                ("multi_profile_bytes", C.c_int64), ("record_pool_bytes", C.c_int64)]
+                ("multi_profile_bytes", C.c_int64), ("record_pool_bytes", C.c_int64),
+                ("pipeline_slots", C.c_int32), ("max_quasars_per_batch", C.c_int64)]
 
 
 class Results(C.Structure):
@@ -103,6 +104,7 @@ SYMBOLS = [
     ("gpdla_default_config", None, [C.POINTER(Config)]),
     ("gpdla_process_batch", C.c_int, [C.POINTER(Model), C.POINTER(Samples), C.POINTER(Spectra),
                                       C.POINTER(Config), C.POINTER(Results), C.c_int]),
+    ("gpdla_default_batch_quasars", C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int]),
     ("gpdla_context_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("gpdla_context_destroy", None, [C.c_void_p]),
     ("gpdla_context_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),

@@ -175,30 +175,17 @@ class Context:
 
     def set_model(self, model: dict):
         """Fields of learned_qso_model_*.mat (process_qsos.m:30-35)."""
-        rw, rwp = _f64(model["rest_wavelengths"])
-        mu, mup = _f64(model["mu"])
-        Mf = np.asfortranarray(model["M"], dtype=np.float64)
-        lo, lop = _f64(model["log_omega"])
-        m = _lib.Model(rw.size, Mf.shape[1], rwp, mup, Mf.ctypes.data_as(_dp), lop,
-                       float(model["log_c_0"]), float(model["log_tau_0"]), float(model["log_beta"]))
+        keep = []
+        m = _model_struct(model, keep)
         _lib.check(self.lib.gpdla_context_set_model(self._h, C.byref(m)))
-        self.k = Mf.shape[1]
+        self.k = int(m.k)
 
     def set_samples(self, samples: dict):
         """Fields of dla_samples.mat (process_qsos.m:38-40)."""
-        off, offp = _f64(samples["offset_samples"])
-        nhi, nhip = _f64(samples["nhi_samples"])
-        keep = [off, nhi]
-        lnp = llp = None
-        if samples.get("log_nhi_samples") is not None:
-            a, lnp = _f64(samples["log_nhi_samples"])
-            keep.append(a)
-        if samples.get("lls_nhi_samples") is not None:
-            a, llp = _f64(samples["lls_nhi_samples"])
-            keep.append(a)
-        s = _lib.Samples(off.size, offp, lnp, nhip, llp)
+        keep = []
+        s = _samples_struct(samples, keep)
         _lib.check(self.lib.gpdla_context_set_samples(self._h, C.byref(s)))
-        self.num_samples = off.size
+        self.num_samples = int(s.num_dla_samples)
 
     def set_timing(self, enabled: bool):
         _lib.check(self.lib.gpdla_context_set_timing(self._h, int(bool(enabled))))
@@ -466,16 +453,13 @@ def resident_bytes_per_quasar(num_pixels: int, k: int, num_samples: int, multi_m
 
 def default_batch_size(num_quasars: int, longest: int, k: int, num_samples: int, slots: int,
                        budget_bytes: float = 96 * 2**30, multi_models: int = 0) -> int:
-    """Quasars per batch of the host pipeline: small enough that ``slots`` batches fit
-    ``budget_bytes`` of HBM next to the record pool and that a run has ~8 batches to overlap (the
-    first upload and the last download are the only copies not hidden behind a sweep), at least
-    128 so that a launch fills the 256 CUs many times over."""
-    per_q = resident_bytes_per_quasar(longest, k, num_samples, multi_models)
-    if multi_models:  # the multi-DLA sweeps build all records of a batch up front
-        per_q += record_bytes_per_quasar(longest, k)
-    cap = max(1, int(budget_bytes / slots / per_q))
-    want = max(128, -(-num_quasars // 8))
-    return max(1, min(cap, want, 4096))
+    """Quasars per batch of the host pipeline (gpdla_default_batch_quasars, the rule the one-shot C
+    entries apply to themselves): small enough that ``slots`` batches fit ``budget_bytes`` of HBM next
+    to the record pool and that a run has ~8 batches to overlap (the first upload and the last
+    download are the only copies not hidden behind a sweep), at least 128 so that a launch fills the
+    256 CUs many times over."""
+    return int(_lib.load().gpdla_default_batch_quasars(int(num_quasars), int(longest), int(k), int(num_samples),
+                                                       int(slots), int(budget_bytes), int(multi_models)))
 
 
 def batch_blocks(num_quasars: int, per_batch: int) -> list:
@@ -548,49 +532,92 @@ def run_pipeline(ctx: "Context", num_blocks: int, inputs, process, download, slo
                 b.close()
 
 
+def _model_struct(model: dict, keep: list) -> "_lib.Model":
+    rw, rwp = _f64(model["rest_wavelengths"])
+    mu, mup = _f64(model["mu"])
+    Mf = np.asfortranarray(model["M"], dtype=np.float64)
+    lo, lop = _f64(model["log_omega"])
+    keep += [rw, mu, Mf, lo]
+    return _lib.Model(rw.size, Mf.shape[1], rwp, mup, Mf.ctypes.data_as(_dp), lop,
+                      float(model["log_c_0"]), float(model["log_tau_0"]), float(model["log_beta"]))
+
+
+def _samples_struct(samples: dict, keep: list) -> "_lib.Samples":
+    off, offp = _f64(samples["offset_samples"])
+    nhi, nhip = _f64(samples["nhi_samples"])
+    keep += [off, nhi]
+    lnp = llp = None
+    if samples.get("log_nhi_samples") is not None:
+        a, lnp = _f64(samples["log_nhi_samples"])
+        keep.append(a)
+    if samples.get("lls_nhi_samples") is not None:
+        a, llp = _f64(samples["lls_nhi_samples"])
+        keep.append(a)
+    return _lib.Samples(off.size, offp, lnp, nhip, llp)
+
+
+def _spectra_struct(csr: dict, lp_no, lp_dla, lp_lls, keep: list) -> "_lib.Spectra":
+    def ptr(a, dt, ct):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data_as(C.POINTER(ct))
+    return _lib.Spectra(
+        csr["z_qsos"].size, ptr(csr["offsets"], np.int64, C.c_int64),
+        ptr(csr["wavelengths"], np.float64, C.c_double), ptr(csr["flux"], np.float64, C.c_double),
+        ptr(csr["noise_variance"], np.float64, C.c_double), ptr(csr["pixel_mask"], np.uint8, C.c_uint8),
+        ptr(csr["z_qsos"], np.float64, C.c_double), ptr(lp_no, np.float64, C.c_double),
+        ptr(lp_dla, np.float64, C.c_double), None if lp_lls is None else ptr(lp_lls, np.float64, C.c_double))
+
+
+def _result_struct(struct_type, out: dict):
+    r = struct_type()
+    for name, _ in struct_type._fields_:
+        if name in out and out[name].size:
+            ct = {"status": C.c_int32, "base_sample_inds": C.c_uint32}.get(name, C.c_double)
+            assert out[name].flags.c_contiguous
+            setattr(r, name, out[name].ctypes.data_as(C.POINTER(ct)))
+    return r
+
+
 def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None = None,
                  params: Parameters | None = None, device: int = 0,
                  log_priors: tuple | None = None, max_quasars_per_batch: int | None = None,
                  pipeline_slots: int = 3, with_samples: bool = True) -> dict:
-    """The ``process_qsos`` script (process_qsos.m:4-250) for a list of quasars.
+    """The ``process_qsos`` script (process_qsos.m:4-250) for a list of quasars: a thin caller of
+    ``gpdla_process_batch``, the one-shot C entry a MEX gateway binds.
 
     ``spectra``: list of dicts with ``wavelengths, flux, noise_variance, pixel_mask, z_qso`` (one
-    entry of the ``all_*`` cell arrays each, after the ``test_ind`` subset of :56-61).
+    entry of the ``all_*`` cell arrays each, after the ``test_ind`` subset of :56-61), or the CSR
+    dict of :func:`spectra_to_csr` (no host copy then).
     ``prior_catalog``: ``{"z_qsos", "dla_ind"}`` of the training release after the Lyman-limit
     filter of :15-25; or pass ``log_priors=(log_priors_no_dla, log_priors_dla)`` directly.
-    Quasars are independent, so the list is swept in HBM-resident batches of at most
-    ``max_quasars_per_batch`` (default: :func:`default_batch_size`) through :func:`run_pipeline`:
-    uploads and downloads overlap the sweeps.  Results do not depend on the batching.
+    Quasars are independent, so the library sweeps the list in HBM-resident batches of at most
+    ``max_quasars_per_batch`` (default: :func:`default_batch_size`) through ``pipeline_slots`` batch
+    slots: uploads and downloads overlap the sweeps.  Results do not depend on the batching.
     Returns the variables the script saves (:236-244)."""
     p = params or Parameters()
-    spectra = list(spectra)
-    nq = len(spectra)
-    z_all = np.array([float(s["z_qso"]) for s in spectra], dtype=np.float64)
+    csr = spectra if isinstance(spectra, dict) else spectra_to_csr(list(spectra))
+    nq = csr["z_qsos"].size
     if log_priors is None:
         if prior_catalog is None:
             raise ValueError("need prior_catalog or log_priors")
-        log_priors = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], z_all, p)
-    lp_no, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
+        log_priors = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], csr["z_qsos"], p)
+    lp_no, lp_dla = (np.ascontiguousarray(x, dtype=np.float64) for x in log_priors)
     S = np.asarray(samples["offset_samples"]).size
-    k = np.asarray(model["M"]).shape[1]
-    if max_quasars_per_batch is None:
-        longest = max((np.asarray(s["wavelengths"]).size for s in spectra), default=1)
-        max_quasars_per_batch = default_batch_size(nq, longest, k, S, pipeline_slots)
-    blocks = batch_blocks(nq, max_quasars_per_batch)
     out = Batch.empty_results(nq, S, with_samples) if nq else {}
-    ctx = Context(device, p)
-    try:
-        ctx.set_model(model)
-        ctx.set_samples(samples)
-        run_pipeline(ctx, len(blocks),
-                     lambda i: (spectra[blocks[i][0]:blocks[i][1]], lp_no[blocks[i][0]:blocks[i][1]],
-                                lp_dla[blocks[i][0]:blocks[i][1]]),
-                     lambda i, batch: batch.process(),
-                     lambda i, batch: batch.download(with_samples, out, blocks[i][0]),
-                     pipeline_slots,
-                     warm=(lambda: prefault(out["sample_log_likelihoods_dla"])) if with_samples and nq else None)
-    finally:
-        ctx.close()
+    if nq:
+        lib = _lib.load()
+        cfg = _config(p)
+        cfg.pipeline_slots = int(pipeline_slots)
+        cfg.max_quasars_per_batch = int(max_quasars_per_batch or 0)
+        keep = []
+        m, s_ = _model_struct(model, keep), _samples_struct(samples, keep)
+        sp = _spectra_struct(csr, lp_no, lp_dla, None, keep)
+        r = _result_struct(_lib.Results, out)
+        _lib.check(lib.gpdla_process_batch(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r),
+                                           int(device)))
+        out["log_priors_no_dla"][:] = lp_no
+        out["log_priors_dla"][:] = lp_dla
     out["num_lines"] = p.num_lines
     out["prior_z_qso_increase"] = p.prior_z_qso_increase
     out["max_z_cut"] = p.max_z_cut
@@ -644,44 +671,31 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
     p = params or MultiParameters()
     md = p.max_dlas
     S = np.asarray(samples["offset_samples"]).size
-    if isinstance(spectra, dict):  # CSR in: one batch
-        nq = spectra["z_qsos"].size
-        blocks = [(0, nq)]
-        take = lambda lo, hi: spectra
-    else:
-        spectra = list(spectra)
-        nq = len(spectra)
-        if max_quasars_per_batch is None:
-            longest = max((np.asarray(s["wavelengths"]).size for s in spectra), default=1)
-            max_quasars_per_batch = default_batch_size(nq, longest, np.asarray(model["M"]).shape[1], S,
-                                                       pipeline_slots, multi_models=md + 1)
-        blocks = batch_blocks(nq, max_quasars_per_batch)
-        take = lambda lo, hi: spectra[lo:hi]
-    lp_no, lp_lls, lp_dla = (np.asarray(x, dtype=np.float64) for x in log_priors)
+    csr = spectra if isinstance(spectra, dict) else spectra_to_csr(list(spectra))
+    nq = csr["z_qsos"].size
+    lp_no, lp_lls, lp_dla = (np.ascontiguousarray(x, dtype=np.float64) for x in log_priors)
     lp_dla = lp_dla.reshape(nq, md)
+    base_ptr = None
     if base_sample_inds is not None:
         base_sample_inds = np.ascontiguousarray(base_sample_inds, dtype=np.uint32)
         if base_sample_inds.shape != (nq, md - 1, S):
             raise _lib.GpdlaError(-1, "base_sample_inds must be [nq, max_dlas-1, S], got "
                                   f"{base_sample_inds.shape}")
+        base_ptr = base_sample_inds.ctypes.data_as(C.POINTER(C.c_uint32))
     out = Batch.empty_results_multi(nq, md, S) if nq else {}
-    ctx = Context(device, p)
-
-    def process(i, batch):
-        lo, hi = blocks[i]
-        ctx.set_first_quasar_index(p.first_quasar_index + lo)
-        batch.process_multi(None if base_sample_inds is None else base_sample_inds[lo:hi])
-
-    try:
-        ctx.set_model(model)
-        ctx.set_samples(samples)
-        run_pipeline(ctx, len(blocks),
-                     lambda i: (take(*blocks[i]), lp_no[blocks[i][0]:blocks[i][1]],
-                                lp_dla[blocks[i][0]:blocks[i][1]], lp_lls[blocks[i][0]:blocks[i][1]]),
-                     process, lambda i, batch: batch.download_multi(True, out, blocks[i][0]),
-                     pipeline_slots,
-                     warm=(lambda: prefault(out["sample_log_likelihoods_dla"], out["sample_log_likelihoods_lls"],
-                                            out["base_sample_inds"])) if nq else None)
-    finally:
-        ctx.close()
+    if nq:
+        lib = _lib.load()
+        cfg = _config(p)
+        cfg.pipeline_slots = int(pipeline_slots)
+        cfg.max_quasars_per_batch = int(max_quasars_per_batch or 0)
+        keep = []
+        m, s_ = _model_struct(model, keep), _samples_struct(samples, keep)
+        sp = _spectra_struct(csr, lp_no, lp_dla, lp_lls, keep)
+        r = _result_struct(_lib.ResultsMulti, out)
+        _lib.check(lib.gpdla_process_batch_multi(C.byref(m), C.byref(s_), C.byref(sp), base_ptr, C.byref(cfg),
+                                                 C.byref(r), int(device)))
+        out["log_priors_no_dla"][:] = lp_no
+        out["log_priors_lls"][:] = lp_lls
+        out["log_priors_dla"][:] = lp_dla
+        out["all_exceptions"][:] = np.where(out["status"] == 1, 1.0, np.nan)  # multi :139, :232
     return out

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -13,7 +14,10 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "../../include/gpdla.h"
 #include "../../include/gpdla_lyman_series.h"
@@ -285,6 +289,8 @@ void gpdla_default_config(gpdla_config *cfg) {
   cfg->contraction_precision = 0;
   cfg->multi_profile_bytes = 0;
   cfg->record_pool_bytes = 0;
+  cfg->pipeline_slots = 0;
+  cfg->max_quasars_per_batch = 0;
 }
 
 /* ------------------------------ context ------------------------------ */
@@ -1058,27 +1064,6 @@ int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) {
   return GPDLA_OK;
 }
 
-int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
-                        const gpdla_spectra *spectra, const gpdla_config *config,
-                        gpdla_results *results, int device_id) {
-  if (!model || !samples || !spectra || !results)
-    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
-  gpdla_context *c = nullptr;
-  gpdla_batch *b = nullptr;
-  int rc = gpdla_context_create(device_id, &c);
-  if (rc) return rc;
-  gpdla_config cfg;
-  gpdla_default_config(&cfg);
-  if (config) cfg = *config;
-  if (!(rc = gpdla_context_set_config(c, &cfg)) && !(rc = gpdla_context_set_model(c, model)) &&
-      !(rc = gpdla_context_set_samples(c, samples)) && !(rc = gpdla_batch_upload(c, spectra, &b)) &&
-      !(rc = gpdla_batch_process(c, b)))
-    rc = gpdla_batch_download(c, b, results);
-  gpdla_batch_destroy(b);
-  gpdla_context_destroy(c);
-  return rc;
-}
-
 /* ------------------------------ stand-alone surfaces ------------------------------ */
 
 int gpdla_voigt(const double *lambdas, int64_t n_padded, double z, double N, int num_lines,
@@ -1564,6 +1549,233 @@ int gpdla_batch_samples_multi_device_ptr(gpdla_batch *b, double **sll_dla, doubl
   return GPDLA_OK;
 }
 
+}  // extern "C"
+
+/* ------------------------------ one-shot entries: the host pipeline ------------------------------ */
+
+namespace {
+
+// Touch every page of a caller-owned output array without changing its contents, so that the
+// device-to-host copies into it do not run at page-fault speed (4 GB/s measured into untouched
+// pageable memory, 10+ once the pages exist).  MADV_POPULATE_WRITE where the kernel has it.
+void prefault_pages(void *p, size_t bytes) {
+  if (!p || !bytes) return;
+  const uintptr_t page = 4096, lo = ((uintptr_t)p + page - 1) & ~(page - 1), hi = ((uintptr_t)p + bytes) & ~(page - 1);
+  if (hi <= lo) return;
+#ifdef MADV_POPULATE_WRITE
+  if (madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_WRITE) == 0) return;
+#endif
+  for (uintptr_t a = lo; a < hi; a += page) {
+    volatile char *c = reinterpret_cast<volatile char *>(a);
+    *c = *c;
+  }
+}
+
+// Three stages over `nblocks` blocks of quasars and `slots` HBM-resident batch slots, the loop of
+// process_qsos.m:88 as a pipeline: an upload thread fills slot i % slots with block i (once the slot's
+// previous results are on the host), the calling thread launches the sweeps in order, a download
+// thread copies block i's results into the caller's arrays.  The library's copy streams run beside
+// the compute stream (gpdla.h, gpdla_batch_download), so while block i is swept block i+1 is
+// uploaded and block i-1 downloaded.  The first error of any stage stops all three; its message
+// becomes the calling thread's gpdla_last_error().
+struct HostPipeline {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<char> uploaded, processed, downloaded;
+  int err = GPDLA_OK;
+  std::string msg;
+
+  explicit HostPipeline(size_t n) : uploaded(n, 0), processed(n, 0), downloaded(n, 0) {}
+  void raise(int rc) {  // called on the failing thread: t_error is that thread's message
+    std::lock_guard<std::mutex> lock(mu);
+    if (!err) {
+      err = rc;
+      msg = t_error;
+    }
+    cv.notify_all();
+  }
+  bool wait(const std::vector<char> &flag, size_t i) {
+    std::unique_lock<std::mutex> lock(mu);
+    cv.wait(lock, [&] { return err || flag[i]; });
+    return !err;
+  }
+  void set(std::vector<char> &flag, size_t i) {
+    std::lock_guard<std::mutex> lock(mu);
+    flag[i] = 1;
+    cv.notify_all();
+  }
+};
+
+template <class Up, class Proc, class Down, class Warm>
+int run_host_pipeline(size_t nblocks, size_t slots, Up up, Proc proc, Down down, Warm warm) {
+  HostPipeline ps(nblocks);
+  auto guarded = [&](auto &&body) {
+    try {
+      body();
+    } catch (const std::exception &e) {
+      fail(GPDLA_ERR_HIP, "host pipeline: %s", e.what());
+      ps.raise(GPDLA_ERR_HIP);
+    }
+  };
+  std::thread uploader([&] {
+    guarded([&] {
+      for (size_t i = 0; i < nblocks; ++i) {
+        if (i >= slots && !ps.wait(ps.downloaded, i - slots)) return;
+        if (int rc = up(i, i % slots)) return ps.raise(rc);
+        ps.set(ps.uploaded, i);
+      }
+    });
+  });
+  std::thread downloader([&] {
+    guarded([&] {
+      warm();
+      for (size_t i = 0; i < nblocks; ++i) {
+        if (!ps.wait(ps.processed, i)) return;
+        if (int rc = down(i, i % slots)) return ps.raise(rc);
+        ps.set(ps.downloaded, i);
+      }
+    });
+  });
+  guarded([&] {
+    for (size_t i = 0; i < nblocks; ++i) {
+      if (!ps.wait(ps.uploaded, i)) return;
+      if (int rc = proc(i, i % slots)) return ps.raise(rc);
+      ps.set(ps.processed, i);
+    }
+  });
+  uploader.join();
+  downloader.join();
+  if (ps.err) return fail(ps.err, "%s", ps.msg.c_str());
+  return GPDLA_OK;
+}
+
+// api.record_bytes_per_quasar / resident_bytes_per_quasar: what a quasar of `npix` stored pixels
+// occupies in a resident batch
+int64_t batch_bytes_per_quasar(int64_t npix, int k, int64_t S, int multi_models) {
+  const double rows = (double)(npix + 8) * (k + 4 + 1 + 3.2) * 8.0;
+  int64_t per_q = (int64_t)(rows + 8.0 * (double)S * std::max(1, 2 * multi_models));
+  if (multi_models)  // the multi-DLA sweeps build all records of a batch up front
+    per_q += (int64_t)(((double)npix / 4.0 + 2.0) * (k <= 20 ? 896 : 1536));
+  return per_q;
+}
+
+struct BlockPlan {
+  size_t slots = 1;
+  std::vector<std::pair<int64_t, int64_t>> blocks;
+};
+
+int plan_blocks(const gpdla_spectra *sp, const gpdla_config &cfg, int k, int64_t S, int multi_models, BlockPlan *plan) {
+  const int64_t nq = sp->num_quasars;
+  if (nq < 1 || !sp->offsets) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
+  int64_t longest = 1;
+  for (int64_t q = 0; q < nq; ++q) {
+    if (sp->offsets[q + 1] < sp->offsets[q])
+      return fail(GPDLA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing (quasar %lld)", (long long)q);
+    longest = std::max(longest, sp->offsets[q + 1] - sp->offsets[q]);
+  }
+  if (cfg.pipeline_slots < 0 || cfg.max_quasars_per_batch < 0)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "pipeline_slots and max_quasars_per_batch must be >= 0");
+  const int slots = cfg.pipeline_slots > 0 ? cfg.pipeline_slots : 3;
+  const int64_t per_batch = cfg.max_quasars_per_batch > 0
+                                ? cfg.max_quasars_per_batch
+                                : gpdla_default_batch_quasars(nq, longest, k, S, slots, 0, multi_models);
+  for (int64_t lo = 0; lo < nq; lo += per_batch) plan->blocks.emplace_back(lo, std::min(lo + per_batch, nq));
+  plan->slots = std::min<size_t>((size_t)slots, plan->blocks.size());
+  return GPDLA_OK;
+}
+
+gpdla_spectra slice_spectra(const gpdla_spectra *sp, int64_t lo, int64_t hi, int md) {
+  gpdla_spectra s = *sp;  // the pixel arrays are indexed through offsets: a block is a pointer shift
+  s.num_quasars = hi - lo;
+  s.offsets = sp->offsets + lo;
+  s.z_qsos = sp->z_qsos + lo;
+  s.log_priors_no_dla = sp->log_priors_no_dla + lo;
+  s.log_priors_dla = sp->log_priors_dla + lo * (md ? md : 1);
+  if (sp->log_priors_lls) s.log_priors_lls = sp->log_priors_lls + lo;
+  return s;
+}
+
+template <typename T>
+T *shifted(T *p, int64_t rows, int64_t width) {
+  return p ? p + rows * width : nullptr;
+}
+
+struct OneShot {  // context + batch slots of a one-shot call, released on every exit path
+  gpdla_context *c = nullptr;
+  std::vector<gpdla_batch *> batches;
+  ~OneShot() {
+    for (gpdla_batch *b : batches) gpdla_batch_destroy(b);
+    gpdla_context_destroy(c);
+  }
+  int open(const gpdla_model *model, const gpdla_samples *samples, const gpdla_config &cfg, int device_id) {
+    int rc = gpdla_context_create(device_id, &c);
+    if (!rc) rc = gpdla_context_set_config(c, &cfg);
+    if (!rc) rc = gpdla_context_set_model(c, model);
+    if (!rc) rc = gpdla_context_set_samples(c, samples);
+    return rc;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int64_t gpdla_default_batch_quasars(int64_t num_quasars, int64_t longest_spectrum, int k, int64_t num_dla_samples,
+                                    int slots, int64_t budget_bytes, int multi_models) {
+  const double budget = budget_bytes > 0 ? (double)budget_bytes : 96.0 * 1073741824.0;
+  const int64_t per_q = batch_bytes_per_quasar(std::max<int64_t>(longest_spectrum, 1), k, num_dla_samples, multi_models);
+  const int64_t cap = std::max<int64_t>(1, (int64_t)(budget / std::max(slots, 1) / (double)per_q));
+  const int64_t want = std::max<int64_t>(128, (num_quasars + 7) / 8);
+  return std::max<int64_t>(1, std::min({cap, want, (int64_t)4096}));
+}
+
+int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
+                        const gpdla_spectra *spectra, const gpdla_config *config,
+                        gpdla_results *results, int device_id) {
+  if (!model || !samples || !spectra || !results)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (spectra->log_priors_lls)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "log_priors_lls given: use gpdla_process_batch_multi");
+  if (!spectra->z_qsos || !spectra->log_priors_no_dla || !spectra->log_priors_dla)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
+  gpdla_config cfg;
+  gpdla_default_config(&cfg);
+  if (config) cfg = *config;
+  BlockPlan plan;
+  int rc = plan_blocks(spectra, cfg, model->k, samples->num_dla_samples, 0, &plan);
+  if (rc) return rc;
+  OneShot os;
+  if ((rc = os.open(model, samples, cfg, device_id))) return rc;
+  os.batches.assign(plan.slots, nullptr);
+  const int64_t S = samples->num_dla_samples;
+  auto up = [&](size_t i, size_t slot) {
+    const gpdla_spectra sp = slice_spectra(spectra, plan.blocks[i].first, plan.blocks[i].second, 0);
+    return os.batches[slot] ? gpdla_batch_reload(os.c, os.batches[slot], &sp) : gpdla_batch_upload(os.c, &sp, &os.batches[slot]);
+  };
+  auto proc = [&](size_t, size_t slot) { return gpdla_batch_process(os.c, os.batches[slot]); };
+  auto down = [&](size_t i, size_t slot) {
+    const int64_t lo = plan.blocks[i].first;
+    gpdla_results r;
+    r.min_z_dlas = shifted(results->min_z_dlas, lo, 1);
+    r.max_z_dlas = shifted(results->max_z_dlas, lo, 1);
+    r.log_likelihoods_no_dla = shifted(results->log_likelihoods_no_dla, lo, 1);
+    r.sample_log_likelihoods_dla = shifted(results->sample_log_likelihoods_dla, lo, S);
+    r.log_likelihoods_dla = shifted(results->log_likelihoods_dla, lo, 1);
+    r.log_posteriors_no_dla = shifted(results->log_posteriors_no_dla, lo, 1);
+    r.log_posteriors_dla = shifted(results->log_posteriors_dla, lo, 1);
+    r.model_posteriors = shifted(results->model_posteriors, lo, 2);
+    r.p_no_dlas = shifted(results->p_no_dlas, lo, 1);
+    r.p_dlas = shifted(results->p_dlas, lo, 1);
+    r.status = shifted(results->status, lo, 1);
+    r.MAP_inds = shifted(results->MAP_inds, lo, 1);
+    r.MAP_z_dlas = shifted(results->MAP_z_dlas, lo, 1);
+    r.MAP_log_nhis = shifted(results->MAP_log_nhis, lo, 1);
+    return gpdla_batch_download(os.c, os.batches[slot], &r);
+  };
+  auto warm = [&] { prefault_pages(results->sample_log_likelihoods_dla, (size_t)spectra->num_quasars * S * sizeof(double)); };
+  return run_host_pipeline(plan.blocks.size(), plan.slots, up, proc, down, warm);
+}
+
 int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
                               const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
                               const gpdla_config *config, gpdla_results_multi *results,
@@ -1571,20 +1783,62 @@ int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *sam
   if (!model || !samples || !spectra || !results)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (!spectra->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
-  gpdla_context *c = nullptr;
-  gpdla_batch *b = nullptr;
-  int rc = gpdla_context_create(device_id, &c);
-  if (rc) return rc;
+  if (!spectra->z_qsos || !spectra->log_priors_no_dla || !spectra->log_priors_dla)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
   gpdla_config cfg;
   gpdla_default_config(&cfg);
   if (config) cfg = *config;
-  if (!(rc = gpdla_context_set_config(c, &cfg)) && !(rc = gpdla_context_set_model(c, model)) &&
-      !(rc = gpdla_context_set_samples(c, samples)) && !(rc = gpdla_batch_upload(c, spectra, &b)) &&
-      !(rc = gpdla_batch_process_multi(c, b, base_sample_inds)))
-    rc = gpdla_batch_download_multi(c, b, results);
-  gpdla_batch_destroy(b);
-  gpdla_context_destroy(c);
-  return rc;
+  const int md = cfg.max_dlas;
+  if (md < 1 || md > 4) return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d outside [1, 4]", md);
+  BlockPlan plan;
+  int rc = plan_blocks(spectra, cfg, model->k, samples->num_dla_samples, md + 1, &plan);
+  if (rc) return rc;
+  OneShot os;
+  if ((rc = os.open(model, samples, cfg, device_id))) return rc;
+  os.batches.assign(plan.slots, nullptr);
+  const int64_t S = samples->num_dla_samples, nbase_row = (int64_t)(md > 1 ? md - 1 : 0) * S;
+  auto up = [&](size_t i, size_t slot) {
+    const gpdla_spectra sp = slice_spectra(spectra, plan.blocks[i].first, plan.blocks[i].second, md);
+    return os.batches[slot] ? gpdla_batch_reload(os.c, os.batches[slot], &sp) : gpdla_batch_upload(os.c, &sp, &os.batches[slot]);
+  };
+  auto proc = [&](size_t i, size_t slot) {
+    const int64_t lo = plan.blocks[i].first;
+    // the draws of the resampling are keyed by the quasar's index in the whole call (multi :467-472)
+    int rc2 = gpdla_context_set_first_quasar_index(os.c, cfg.first_quasar_index + lo);
+    if (rc2) return rc2;
+    return gpdla_batch_process_multi(os.c, os.batches[slot], base_sample_inds ? base_sample_inds + lo * nbase_row : nullptr);
+  };
+  auto down = [&](size_t i, size_t slot) {
+    const int64_t lo = plan.blocks[i].first;
+    gpdla_results_multi r;
+    r.min_z_dlas = shifted(results->min_z_dlas, lo, 1);
+    r.max_z_dlas = shifted(results->max_z_dlas, lo, 1);
+    r.log_likelihoods_no_dla = shifted(results->log_likelihoods_no_dla, lo, 1);
+    r.sample_log_likelihoods_dla = shifted(results->sample_log_likelihoods_dla, lo, (int64_t)md * S);
+    r.sample_log_likelihoods_lls = shifted(results->sample_log_likelihoods_lls, lo, S);
+    r.log_likelihoods_dla = shifted(results->log_likelihoods_dla, lo, md);
+    r.log_likelihoods_lls = shifted(results->log_likelihoods_lls, lo, 1);
+    r.log_posteriors_no_dla = shifted(results->log_posteriors_no_dla, lo, 1);
+    r.log_posteriors_lls = shifted(results->log_posteriors_lls, lo, 1);
+    r.log_posteriors_dla = shifted(results->log_posteriors_dla, lo, md);
+    r.model_posteriors = shifted(results->model_posteriors, lo, 2 + md);
+    r.p_no_dlas = shifted(results->p_no_dlas, lo, 1);
+    r.p_lls = shifted(results->p_lls, lo, 1);
+    r.p_dlas = shifted(results->p_dlas, lo, 1);
+    r.MAP_z_dlas = shifted(results->MAP_z_dlas, lo, (int64_t)md * md);
+    r.MAP_log_nhis = shifted(results->MAP_log_nhis, lo, (int64_t)md * md);
+    r.MAP_inds = shifted(results->MAP_inds, lo, (int64_t)md * md);
+    r.base_sample_inds = shifted(results->base_sample_inds, lo, nbase_row);
+    r.status = shifted(results->status, lo, 1);
+    return gpdla_batch_download_multi(os.c, os.batches[slot], &r);
+  };
+  auto warm = [&] {
+    const size_t nq = (size_t)spectra->num_quasars;
+    prefault_pages(results->sample_log_likelihoods_dla, nq * md * S * sizeof(double));
+    prefault_pages(results->sample_log_likelihoods_lls, nq * S * sizeof(double));
+    prefault_pages(results->base_sample_inds, nq * nbase_row * sizeof(uint32_t));
+  };
+  return run_host_pipeline(plan.blocks.size(), plan.slots, up, proc, down, warm);
 }
 
 void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {

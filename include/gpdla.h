@@ -38,7 +38,7 @@ typedef enum {
 } gpdla_status;
 
 #define GPDLA_MAX_K 40
-#define GPDLA_ABI_VERSION 5
+#define GPDLA_ABI_VERSION 6
 
 int gpdla_abi_version(void);
 /* Human-readable text of the most recent error on this thread (never NULL). */
@@ -136,6 +136,12 @@ typedef struct {
    * its records: 0.9 KB per K-step for k <= 20, but 29 KB for 20 < k <= 40 -- 228 GB for a DR12Q
    * shard.  Results do not depend on it.  0 = default (16 GiB). */
   int64_t record_pool_bytes;
+  /* one-shot entries (gpdla_process_batch, gpdla_process_batch_multi) only: the quasars of a call are
+   * swept in HBM-resident batches of at most max_quasars_per_batch through pipeline_slots batch slots
+   * (upload of batch i+1 / sweep of batch i / download of batch i-1 overlap).  0 = defaults: 3 slots,
+   * gpdla_default_batch_quasars() quasars.  Results do not depend on either. */
+  int32_t pipeline_slots;
+  int64_t max_quasars_per_batch;
 } gpdla_config;
 
 /* Fills a gpdla_config with the reference's defaults (set_parameters.m / set_parameters_multi.m). */
@@ -168,10 +174,27 @@ typedef struct {
   double *MAP_log_nhis;               /* [nq] */
 } gpdla_results;
 
-/* One-shot: host buffers in, host buffers out (uploads, sweeps, downloads). */
+/* One-shot: host buffers in, host buffers out -- the loop of process_qsos.m:88 over ALL quasars of the
+ * call.  Inside, the quasars are cut into blocks (config->max_quasars_per_batch) that go through
+ * config->pipeline_slots batch slots in HBM: one library thread uploads block i+1 (the CSR arrays are
+ * sliced in place, nothing is copied on the host) and another downloads block i-1 straight into the
+ * caller's arrays while the calling thread has block i swept, so the PCIe copies hide behind the
+ * sweeps (INTEGRATION.md section 3 states the measured rate against the resident form).  Host memory
+ * beyond the caller's arrays: per-quasar bookkeeping of `slots` blocks.  The call owns a context for
+ * its duration (streams, model, samples, slots) and returns when every result is in the caller's
+ * arrays; on an error no result array is meaningful.  Results are bit-identical for every batching. */
 int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
                         const gpdla_spectra *spectra, const gpdla_config *config,
                         gpdla_results *results, int device_id);
+
+/* Quasars per batch the one-shot entries (and the Python file pipeline) use by default: small enough
+ * that `slots` batches of quasars of `longest_spectrum` pixels fit budget_bytes of HBM (0 = 96 GiB)
+ * next to the record pool, and that a run has ~8 batches to overlap, at least 128 so that a launch
+ * fills the 256 CUs many times over, at most 4096.  multi_models = max_dlas + 1 for the multi-DLA
+ * driver (its batches also hold 2 x models sample tables and all their records), else 0.  No GPU. */
+int64_t gpdla_default_batch_quasars(int64_t num_quasars, int64_t longest_spectrum, int k,
+                                    int64_t num_dla_samples, int slots, int64_t budget_bytes,
+                                    int multi_models);
 
 /* ---------------------------------------------------------------------------------------------
  * Resident form: a context owns a device, a stream, the replicated model + samples and scratch;
@@ -266,6 +289,9 @@ typedef struct {
   int32_t *status;                        /* [nq] 1 = all_exceptions (:232) */
 } gpdla_results_multi;
 
+/* One-shot form, pipelined like gpdla_process_batch (blocks of quasars through batch slots; block b's
+ * draws are keyed by config->first_quasar_index + its first quasar, so the batching does not change
+ * them). */
 int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
                               const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
                               const gpdla_config *config, gpdla_results_multi *results,

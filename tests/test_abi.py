@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_typed(lib):
     for n in names:
         assert hasattr(lib, n), f"libgpdla.so does not export {n}"
         assert n in typed, f"{n} has no ctypes signature in _lib.SYMBOLS"
-    assert lib.gpdla_abi_version() == 5
+    assert lib.gpdla_abi_version() == 6
 
 
 def test_struct_layouts_match_header(lib):
@@ -44,6 +44,7 @@ def test_struct_layouts_match_header(lib):
     assert (cfg.prev_tau_0, cfg.prev_beta) == (0.0023, 3.65)
     assert cfg.rng_seed == 0x9E3779B97F4A7C15 and cfg.first_quasar_index == 0
     assert cfg.contraction_precision == 0 and cfg.multi_profile_bytes == 0
+    assert cfg.pipeline_slots == 0 and cfg.max_quasars_per_batch == 0
 
 
 C_CONSUMER = r"""
@@ -67,6 +68,7 @@ int main(void) {
   OFF(gpdla_config, width); OFF(gpdla_config, max_dlas); OFF(gpdla_config, min_z_separation);
   OFF(gpdla_config, rng_seed); OFF(gpdla_config, contraction_precision);
   OFF(gpdla_config, multi_profile_bytes); OFF(gpdla_config, record_pool_bytes);
+  OFF(gpdla_config, pipeline_slots); OFF(gpdla_config, max_quasars_per_batch);
   OFF(gpdla_results, status); OFF(gpdla_results, MAP_log_nhis);
   OFF(gpdla_results_multi, base_sample_inds); OFF(gpdla_results_multi, status);
   gpdla_config cfg;
@@ -75,6 +77,8 @@ int main(void) {
   if (gpdla_abi_version() != GPDLA_ABI_VERSION) return 2;
   if (cfg.width != 3 || cfg.num_lines != 3 || cfg.max_dlas != 4 || cfg.min_lambda != 911.75) return 3;
   if (cfg.multi_profile_bytes != 0 || cfg.record_pool_bytes != 0) return 4;
+  if (cfg.pipeline_slots != 0 || cfg.max_quasars_per_batch != 0) return 4;
+  if (gpdla_default_batch_quasars(2048, 1500, 20, 10000, 3, 0, 0) != 256) return 7;
   uint32_t ctr[4] = {0, 0, 0, 0}, key[2] = {0, 0}, out[4];
   gpdla_debug_philox4x32_10(ctr, key, out);
   if (out[0] != 0x6627e8d5u) return 5;
@@ -161,6 +165,52 @@ def test_argument_validation_needs_no_gpu(lib):
     assert rc == -1 and b"num_lines" in lib.gpdla_last_error()
 
 
+def _one_shot_args(nq=3, n=40, k=4, S=8):
+    """Host arrays + structs for a gpdla_process_batch call (kept alive by the returned list)."""
+    from gp_dla_detection_amd import api, synthetic
+    model = synthetic.make_model(k)
+    samples = synthetic.make_samples(S)
+    spectra = synthetic.make_spectra(nq, n, model, first_index=5)
+    csr = api.spectra_to_csr(spectra)
+    keep = [csr]
+    m, s_ = api._model_struct(model, keep), api._samples_struct(samples, keep)
+    sp = api._spectra_struct(csr, np.full(nq, -1.0), np.full(nq, -2.0), None, keep)
+    out = api.Batch.empty_results(nq, S)
+    r = api._result_struct(_lib.Results, out)
+    cfg = _lib.Config()
+    _lib.load().gpdla_default_config(C.byref(cfg))
+    return m, s_, sp, cfg, r, keep, out
+
+
+def test_one_shot_entry_validates_before_it_touches_the_gpu(lib):
+    """gpdla_process_batch: bad batching fields, decreasing offsets and a multi-DLA prior array are
+    refused with GPDLA_ERR_INVALID_ARGUMENT whether or not a GPU exists."""
+    m, s_, sp, cfg, r, keep, _ = _one_shot_args()
+    cfg.pipeline_slots = -1
+    assert lib.gpdla_process_batch(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r), 0) == -1
+    assert b"pipeline_slots" in lib.gpdla_last_error()
+    cfg.pipeline_slots = 0
+    sp.offsets[2] = sp.offsets[1] - 1
+    assert lib.gpdla_process_batch(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r), 0) == -1
+    assert b"non-decreasing" in lib.gpdla_last_error()
+    m, s_, sp, cfg, r, keep, _ = _one_shot_args()
+    sp.log_priors_lls = sp.log_priors_no_dla
+    assert lib.gpdla_process_batch(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r), 0) == -1
+    assert lib.gpdla_process_batch(C.byref(m), C.byref(s_), None, C.byref(cfg), C.byref(r), 0) == -1
+
+
+def test_default_batch_rule(lib):
+    """gpdla_default_batch_quasars: ~8 batches per run, >= 128 and <= 4096 quasars, `slots` batches within
+    the HBM budget; the multi-DLA driver's batches are smaller (2 x models sample tables + records)."""
+    f = lib.gpdla_default_batch_quasars
+    assert f(2048, 1500, 20, 10000, 3, 0, 0) == 256
+    assert f(100, 1500, 20, 10000, 3, 0, 0) == 128
+    assert f(10 ** 6, 1500, 20, 10000, 3, 0, 0) == 4096
+    assert f(10 ** 6, 1500, 40, 10000, 3, 2 ** 30, 0) < 800
+    assert f(10 ** 6, 1500, 20, 10000, 3, 2 ** 33, 5) < f(10 ** 6, 1500, 20, 10000, 3, 2 ** 33, 0)
+    assert f(1, 0, 20, 10, 0, 0, 0) >= 1
+
+
 def test_no_cpu_fallback(lib):
     import torch
     if torch.cuda.is_available():
@@ -172,6 +222,11 @@ def test_no_cpu_fallback(lib):
     assert rc == -2, "without a GPU the library must fail loudly, not compute on the CPU"
     h = C.c_void_p()
     assert lib.gpdla_context_create(0, C.byref(h)) == -2
+    # the one-shot entry (its upload / download threads never start without a device)
+    m, s_, sp, cfg, r, keep, out = _one_shot_args()
+    assert lib.gpdla_process_batch(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r), 0) == -2
+    assert b"no CPU fallback" in lib.gpdla_last_error()
+    assert np.isnan(out["log_likelihoods_dla"]).all()
 
 
 def test_prior_matches_counting_definition():

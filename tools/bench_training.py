@@ -18,6 +18,8 @@ ap.add_argument("--quasars", type=int, default=5000)
 ap.add_argument("--pixels", type=int, default=1217)
 ap.add_argument("--k", type=int, default=20)
 ap.add_argument("--forest-lines", type=int, default=0, help="> 1: the mean-flux model's objective (objective_lyseries.m)")
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle leg (profiling passes)")
 args = ap.parse_args()
 rng = np.random.default_rng(0)
 nq, G, k = args.quasars, args.pixels, args.k
@@ -32,11 +34,14 @@ if args.forest_lines > 1:
     t.set_lyseries(args.forest_lines)
 t.objective(x)
 t0 = time.perf_counter()
-reps = 5
+reps = args.reps
 for _ in range(reps):
     f, g = t.objective(x)
 gpu_s = (time.perf_counter() - t0) / reps
 t.close()
+if args.no_cpu:
+    print(json.dumps({"quasars": nq, "pixels": G, "k": k, "gpu_seconds_per_eval": gpu_s, "forest_lines": args.forest_lines}))
+    sys.exit(0)
 # CPU oracle on the threads this job may really use: the cgroup quota, not the host's CPU count
 # (a GPU box hands a 16-CPU slice of a 256-CPU host to a one-GPU job; 256 OpenMP threads on 16 CPUs
 # measure oversubscription, not the oracle -- bench.py:cpu_baseline does the same)
