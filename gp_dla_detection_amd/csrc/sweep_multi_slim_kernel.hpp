@@ -185,7 +185,14 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
       constexpr int kXS = 4;
       constexpr int kT0[4] = {0, 4, 7, 10}, kT1[4] = {4, 7, 10, 13};
       if (tt == kXS && c + 2 < nchunks) issue_private(c + 2);
-      if (rn < m.steps) {
+      // Past the quasar's last K-step (only the last chunk can be short) the kernel leaves BOTH loops in
+      // one jump.  Guarding every K-step by itself, or breaking out of the chunk only, computes the
+      // same thing but leaves paths in the control-flow graph -- K-step 0 skipped and K-step 4 run, or a
+      // short chunk followed by another chunk -- on which a gather slot is consumed with fewer than
+      // (kAhead - 1) ND younger requests behind it: paths that never execute, but that the static check
+      // of the hand-counted waits (tools/check_vmem_hazard.py) cannot tell from real ones.
+      if (rn >= m.steps) goto k_loop_done;
+      {
         const double *tl = tbuf + (size_t)tt * kSlimStepTiles;
         const double *mine = mine0 + (size_t)tt * kSlimRec;
         const double2 p01 = *reinterpret_cast<const double2 *>(mine);
@@ -255,6 +262,7 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
 #endif
   }
 
+k_loop_done:
   // The last four K-steps requested profile values nobody multiplies.  They were issued by inline
   // assembly, so the compiler does not know that their destination registers are still awaited and
   // hands them to the epilogue: a load landing late would overwrite whatever lives there by then.
@@ -267,6 +275,10 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
     for (int j = 0; j < ND; ++j) asm volatile("" : "+v"(raw[t][j]));  // (the registers stay theirs up to here)
   }
 #endif
+  // a short last chunk has jumped over its chunk-end barrier: the epilogue below reuses the LDS the
+  // other waves' last K-steps read (all waves of a block sweep the same quasar and leave the same way)
+  glds_wait();
+  __syncthreads();
   double logd_sum = log(dprod) + (double)dexp * 0.6931471805599453;
   quad_sum += __shfl_xor(quad_sum, 16);
   quad_sum += __shfl_xor(quad_sum, 32);
