@@ -58,7 +58,7 @@ def algorithmic_flops(n, k: int):
 
 def lib_sha256() -> str:
     from gp_dla_detection_amd import _lib
-    with open(_lib.LIB_PATH, "rb") as f:
+    with open(_lib.lib_path(), "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()
 
 
@@ -509,6 +509,7 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, "
                          f"profiles/pmc_latest.json{', tag ' + traffic_tag if traffic_tag else ''}; null unless "
                          "measured on this libgpdla.so and workload)",
+                         # (GPDLA_EXPANDED_RECORDS only means something to libgpdla_legacy.so, loaded through GPDLA_LIB_PATH by the A/B tools)
                          "kernel": ("k_sweep_slim" if args.k <= 20 and args.contraction == "f64"
                                     and not os.environ.get("GPDLA_EXPANDED_RECORDS") else
                                     ("k_sweep_split" if os.environ.get("GPDLA_EXPANDED_RECORDS") else "k_sweep_split_slim")

@@ -12,8 +12,17 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-# GPDLA_LIB_PATH: diagnostic override (ablation builds made by tools/ablate.sh)
-LIB_PATH = os.environ.get("GPDLA_LIB_PATH") or os.path.join(CSRC, "libgpdla.so")
+#: the product library
+DEFAULT_LIB_PATH = os.path.join(CSRC, "libgpdla.so")
+# GPDLA_LIB_PATH: diagnostic override, read when the library is loaded (ablation builds made by
+# tools/ab_build.sh / tools/ablate.sh; libgpdla_legacy.so for the bit-identity tests)
+LIB_PATH = os.environ.get("GPDLA_LIB_PATH") or DEFAULT_LIB_PATH
+
+
+def lib_path() -> str:
+    """The library load() opens: GPDLA_LIB_PATH if set (read at call time, so a child process may
+    set it after this module was imported), else the in-tree product library."""
+    return os.environ.get("GPDLA_LIB_PATH") or DEFAULT_LIB_PATH
 
 # -no-hip-rt: libgpdla.so does NOT carry its own DT_NEEDED on libamdhip64.  A process must hold
 # exactly one HIP runtime (a second copy cannot open the GPU, and a hipStream_t only means
@@ -22,6 +31,11 @@ LIB_PATH = os.environ.get("GPDLA_LIB_PATH") or os.path.join(CSRC, "libgpdla.so")
 # C / MEX consumer.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
                "-std=c++17", "-no-hip-rt", "-Wno-inline-asm"]
+
+#: the second library: the same source with the superseded kernels and their environment switches
+#: compiled in (csrc/gpdla.hip, GPDLA_WITH_LEGACY).  Only bit-identity tests and A/B tools load it,
+#: through GPDLA_LIB_PATH; nothing in the package does.
+LEGACY_LIB_PATH = os.path.join(CSRC, "libgpdla_legacy.so")
 
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
@@ -147,16 +161,34 @@ def build(force: bool = False, verbose: bool = False) -> str:
     import glob
     srcs = (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))
             + glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
-    if not force and os.path.exists(LIB_PATH):
-        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
-            return LIB_PATH
-    cmd = ["hipcc", *HIPCC_FLAGS, os.path.join(CSRC, "gpdla.hip"), "-o", LIB_PATH]
+    if not force and os.path.exists(DEFAULT_LIB_PATH):
+        if all(os.path.getmtime(DEFAULT_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+            return DEFAULT_LIB_PATH
+    cmd = ["hipcc", *HIPCC_FLAGS, os.path.join(CSRC, "gpdla.hip"), "-o", DEFAULT_LIB_PATH]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout, res.stderr)
     if res.returncode:
         raise RuntimeError("hipcc failed building libgpdla.so:\n" + res.stderr)
-    return LIB_PATH
+    return DEFAULT_LIB_PATH
+
+
+def build_legacy(force: bool = False, verbose: bool = False) -> str:
+    """Compile libgpdla_legacy.so: csrc/gpdla.hip with -DGPDLA_WITH_LEGACY (the pre-expanded-record
+    sweeps, the round-1/-3 training kernels and the GPDLA_* environment switches that select them)."""
+    import glob
+    srcs = (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))
+            + glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
+    if not force and os.path.exists(LEGACY_LIB_PATH):
+        if all(os.path.getmtime(LEGACY_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+            return LEGACY_LIB_PATH
+    cmd = ["hipcc", *HIPCC_FLAGS, "-DGPDLA_WITH_LEGACY", os.path.join(CSRC, "gpdla.hip"), "-o", LEGACY_LIB_PATH]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(res.stdout, res.stderr)
+    if res.returncode:
+        raise RuntimeError("hipcc failed building libgpdla_legacy.so:\n" + res.stderr)
+    return LEGACY_LIB_PATH
 
 
 def _preload_hip_runtime():
@@ -186,12 +218,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = lib_path()
+    if not os.path.exists(path):
         raise FileNotFoundError(
-            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
             "gp_dla_detection_amd has no CPU fallback.")
     _preload_hip_runtime()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = restype

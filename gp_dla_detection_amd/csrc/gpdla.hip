@@ -31,6 +31,23 @@
 
 using namespace gpdla;
 
+// Superseded kernels and the environment switches that select them live in a SECOND library only:
+// libgpdla_legacy.so = this file built with -DGPDLA_WITH_LEGACY (gp_dla_detection_amd/_lib.py:
+// build_legacy), loaded through GPDLA_LIB_PATH by tests/test_gpu_record_classes.py, tools/ab*.sh and
+// tools/check_training_legacy.py for bit-identity tests and A/B timing.  The product library reads no
+// environment variable: no stray variable can select a slower kernel, and the superseded kernels
+// are not in its code object.
+//   GPDLA_EXPANDED_RECORDS  the sweeps on pre-expanded records (k_sweep / k_sweep_split / k_sweep_multi*)
+//   GPDLA_SPLIT_LEGACY      20 < k <= 40 with every wave of a group repeating the Voigt / weight arithmetic
+//   GPDLA_TRAIN_SPLITS      "H,H2,GS": the three splits of the training objective
+//   GPDLA_TRAIN_FACTOR_LDS  k_train_factor<40> (LDS broadcasts) instead of k_train_factor16<40>
+//   GPDLA_TRAIN_LEGACY      the round-1 training kernel (one block per slot of quasars)
+#ifdef GPDLA_WITH_LEGACY
+#define GPDLA_LEGACY_SWITCH(name, var) static const bool name = std::getenv(var) != nullptr
+#else
+#define GPDLA_LEGACY_SWITCH(name, var) constexpr bool name = false
+#endif
+
 namespace {
 
 thread_local std::string t_error = "";
@@ -920,11 +937,11 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   const int num_lines = c->cfg.num_lines;
   // k <= 20, three lines, fp64: slim step records, vech(m m') formed inside the sweep (k_sweep_slim).
   // GPDLA_EXPANDED_RECORDS=1 (diagnostic): the pre-expanded records of k_sweep, for A/B timing.
-  static const bool expanded = std::getenv("GPDLA_EXPANDED_RECORDS") != nullptr;
+  GPDLA_LEGACY_SWITCH(expanded, "GPDLA_EXPANDED_RECORDS");
   const bool f32 = c->cfg.contraction_precision == 1;
   // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k_sweep form of 20 < k <= 40 in which every wave of a group
   // repeats the Voigt/weight arithmetic, for A/B timing against k_sweep_split
-  static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
+  GPDLA_LEGACY_SWITCH(legacy, "GPDLA_SPLIT_LEGACY");
   const bool slim = b->k <= 20 && num_lines == 3 && !f32 && !expanded;
   // 20 < k <= 40, fp64: slim records as well (k_sweep_split_slim); GPDLA_EXPANDED_RECORDS=1 keeps
   // k_sweep_split on the pre-expanded 29-KiB records
@@ -968,15 +985,25 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
     if (slim) {
       rc = launch_sweep_slim(c, b, sa);
     } else if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
-      if (!f32) rc = three ? launch_sweep<double, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
+      if (!f32) {
+#ifdef GPDLA_WITH_LEGACY
+        rc = three ? launch_sweep<double, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
+#else  // (three lines in fp64 take k_sweep_slim above: the pre-expanded three-line form is in libgpdla_legacy.so only)
+        rc = launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
+#endif
+      }
       else rc = three ? launch_sweep<float, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
     } else if (slim40) {  // 52 w-tiles (<= 820 columns) + 3 u-tiles split over the 8 waves of a block
       rc = three ? launch_sweep_split_slim<3>(c, b, sa) : launch_sweep_split_slim<0>(c, b, sa);
-    } else if (!f32) {  // the same tiles pre-expanded in the records, split over the 4 waves of a sample group
+    } else if (!f32) {  // (legacy library only) the same tiles pre-expanded in the records, split over the 4 waves of a sample group
+#ifdef GPDLA_WITH_LEGACY
       if (legacy)
         rc = three ? launch_sweep<double, 8, 14, 4, 2, 52, 3>(c, b, sa) : launch_sweep<double, 8, 14, 4, 1, 52, 0>(c, b, sa);
       else
         rc = three ? launch_sweep_split<3>(c, b, sa) : launch_sweep_split<0>(c, b, sa);
+#else
+      rc = fail(GPDLA_ERR_UNSUPPORTED, "pre-expanded records at 20 < k <= 40 are in libgpdla_legacy.so only");
+#endif
     } else {  // fp32: 224 accumulator registers fit one wave (4-wave blocks, one wave per SIMD)
       rc = three ? launch_sweep<float, 4, 56, 1, 4, 52, 3>(c, b, sa) : launch_sweep<float, 4, 56, 1, 4, 52, 0>(c, b, sa);
     }
@@ -1238,6 +1265,7 @@ int launch_sweep_multi_split_slim(gpdla_context *c, const SweepMultiArgs &args) 
   }
 }
 
+#ifdef GPDLA_WITH_LEGACY
 // 20 < k <= 40: the roles of a sample group share the gathers and weights (k_sweep_multi_split)
 int launch_sweep_multi_split(gpdla_context *c, const SweepMultiArgs &args) {
   switch (args.mode == 0 ? 1 : args.mode) {
@@ -1248,6 +1276,7 @@ int launch_sweep_multi_split(gpdla_context *c, const SweepMultiArgs &args) {
     default: return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d > 4", args.mode);
   }
 }
+#endif
 
 // Result tables of a multi-DLA batch (allocated on first use, kept while the batch does not grow)
 // and the context's profile table.
@@ -1337,8 +1366,8 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
   // are built up front, one group)
   // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k <= 40 form in which every wave of a group gathers and
   // weighs for itself; GPDLA_EXPANDED_RECORDS=1 (diagnostic): the sweeps on pre-expanded records
-  static const bool legacy = std::getenv("GPDLA_SPLIT_LEGACY") != nullptr;
-  static const bool expanded = std::getenv("GPDLA_EXPANDED_RECORDS") != nullptr;
+  GPDLA_LEGACY_SWITCH(legacy, "GPDLA_SPLIT_LEGACY");
+  GPDLA_LEGACY_SWITCH(expanded, "GPDLA_EXPANDED_RECORDS");
   const RecordClass cls = expanded ? kRecExpanded : b->k <= 20 ? kRecSlim20 : !legacy ? kRecSlim40 : kRecExpanded;
   if ((rc = plan_records(c, b, record_class_doubles(cls, b->ntiles, false), true))) return rc;
   if ((rc = launch_prepare(c, b, true))) return rc;
@@ -1402,10 +1431,14 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
         sa.sample_ll_lls = mb.sll_lls;
         sa.ll_no_dla = mb.ll_no;
         sa.pix = b->d_pix;
+#ifdef GPDLA_WITH_LEGACY
         rc = cls == kRecSlim20 ? launch_sweep_multi_slim(c, sa)
              : b->k <= 20 ? launch_sweep_multi<14, 1, 8, 13>(c, b, sa)
              : legacy ? launch_sweep_multi<14, 4, 1, 52>(c, b, sa)
              : cls == kRecSlim40 ? launch_sweep_multi_split_slim(c, sa) : launch_sweep_multi_split(c, sa);
+#else
+        rc = cls == kRecSlim20 ? launch_sweep_multi_slim(c, sa) : launch_sweep_multi_split_slim(c, sa);
+#endif
         if (rc) return rc;
       }
       // evidence, MAP, early-exit flags for the quasars of this sub-batch
@@ -1980,7 +2013,11 @@ TrainDims train_dims(const gpdla_training *t, int k) {
   d.H2 = 24;  // 20 row blocks x 24 = 480
   d.GS = 24;  // 20 pixel blocks x 24 = 480 blocks of 4 waves (59 KiB of LDS each: two per CU)
   // (diagnostic: GPDLA_TRAIN_SPLITS="H,H2,GS" overrides the three splits)
+#ifdef GPDLA_WITH_LEGACY
   static const char *splits = std::getenv("GPDLA_TRAIN_SPLITS");
+#else
+  constexpr const char *splits = nullptr;
+#endif
   int h = 0, h2 = 0, gs = 0;
   if (splits && std::sscanf(splits, "%d,%d,%d", &h, &h2, &gs) == 3 && h > 0 && h2 > 0 && gs > 0 && h <= 64 &&
       h2 <= 256 && gs <= 256) {
@@ -2042,11 +2079,15 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
   fa.group_stride = strideD;
   // k <= 40: the per-quasar algebra in registers (k_train_factor16); GPDLA_TRAIN_FACTOR_LDS=1 (diagnostic): the
   // round-3 kernel, which stays the k <= 20 form
-  static const bool factor_lds = std::getenv("GPDLA_TRAIN_FACTOR_LDS") != nullptr;
+  GPDLA_LEGACY_SWITCH(factor_lds, "GPDLA_TRAIN_FACTOR_LDS");
   const dim3 factor_grid((unsigned)((d.NQ16 * 16 + TrF<KMAX>::FQ - 1) / TrF<KMAX>::FQ));
   if constexpr (KMAX == 40) {
+#ifdef GPDLA_WITH_LEGACY
     if (factor_lds) hipLaunchKernelGGL(k_train_factor<KMAX>, factor_grid, dim3(256), 0, st, fa);
-    else hipLaunchKernelGGL(k_train_factor16<KMAX>, factor_grid, dim3(kTrF16Threads), 0, st, fa);
+    else
+#endif
+      hipLaunchKernelGGL(k_train_factor16<KMAX>, factor_grid, dim3(kTrF16Threads), 0, st, fa);
+    (void)factor_lds;
   } else {
     hipLaunchKernelGGL(k_train_factor<KMAX>, factor_grid, dim3(256), 0, st, fa);
   }
@@ -2280,9 +2321,10 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
   // evaluation (k <= 20: one 16-tile group per contraction step; 20 < k <= 40: four).
   // GPDLA_TRAIN_LEGACY=1 (diagnostic cross-check): one block per slot of quasars, each slot adding
   // into its own copy of g, slots summed in order -- deterministic too (round 1 used fp64 atomics).
-  static const bool legacy = std::getenv("GPDLA_TRAIN_LEGACY") != nullptr;
+  GPDLA_LEGACY_SWITCH(legacy, "GPDLA_TRAIN_LEGACY");
   std::memcpy(t->h_stage, x, (size_t)nx * sizeof(double));
   if (!legacy) return training_objective_mfma(t, k, f, g);
+#ifdef GPDLA_WITH_LEGACY
   if (t->lines.nfl > 1) return fail(GPDLA_ERR_UNSUPPORTED, "GPDLA_TRAIN_LEGACY has no Lyman-series objective");
   const int num_slots = (int)std::min<int64_t>(t->nq, 512);
   const int64_t slot_n = nx + 1;  // [g | f]
@@ -2333,6 +2375,9 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
   g[G * (k + 1) + 1] += a.tau_0 * (a.tau_0 - tau_0_mu) / (tau_0_sigma * tau_0_sigma);
   g[G * (k + 1) + 2] += a.beta * (a.beta - beta_mu) / (beta_sigma * beta_sigma);
   return GPDLA_OK;
+#else
+  return GPDLA_OK;  // (not reached: `legacy` is false in the product library)
+#endif
 }
 
 }  // extern "C"

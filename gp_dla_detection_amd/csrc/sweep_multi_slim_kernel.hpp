@@ -191,7 +191,11 @@ __global__ __launch_bounds__(512) void k_sweep_multi_slim(SweepMultiArgs a) {
       // short chunk followed by another chunk -- on which a gather slot is consumed with fewer than
       // (kAhead - 1) ND younger requests behind it: paths that never execute, but that the static check
       // of the hand-counted waits (tools/check_vmem_hazard.py) cannot tell from real ones.
+#ifdef MSLIM_EXP_GUARD_EACH  // (A/B: the round-4 form, every K-step guarded by itself)
+      if (rn < m.steps)
+#else
       if (rn >= m.steps) goto k_loop_done;
+#endif
       {
         const double *tl = tbuf + (size_t)tt * kSlimStepTiles;
         const double *mine = mine0 + (size_t)tt * kSlimRec;

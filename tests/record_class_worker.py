@@ -1,6 +1,7 @@
 """Worker of test_gpu_record_classes.py: one seeded case run in a clean child process (forked from
 conftest.py's fork server, which predates any GPU use) with the library's diagnostic environment
-switches set BEFORE libgpdla.so reads them (they are read once per process)."""
+switches -- and GPDLA_LIB_PATH = libgpdla_legacy.so, the only library that knows them -- set BEFORE the
+library is loaded (both are read once per process)."""
 import os
 
 import numpy as np

@@ -101,8 +101,8 @@ def test_c_consumer_links_against_the_header(lib, tmp_path):
     exe = tmp_path / "consumer"
     hip_rt = os.path.dirname(_lib._preload_hip_runtime()._name)
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
-                    str(src), "-o", str(exe), _lib.LIB_PATH, "-L", hip_rt, "-lamdhip64",
-                    f"-Wl,-rpath,{os.path.dirname(_lib.LIB_PATH)}", f"-Wl,-rpath,{hip_rt}"],
+                    str(src), "-o", str(exe), _lib.DEFAULT_LIB_PATH, "-L", hip_rt, "-lamdhip64",
+                    f"-Wl,-rpath,{os.path.dirname(_lib.DEFAULT_LIB_PATH)}", f"-Wl,-rpath,{hip_rt}"],
                    check=True, capture_output=True)
     res = subprocess.run([str(exe)], capture_output=True, text=True)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)

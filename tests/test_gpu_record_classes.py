@@ -1,10 +1,13 @@
 """The slim step records (vech(m m') formed inside the sweep) against the pre-expanded records they
 replace: k_sweep_slim vs k_sweep and k_sweep_multi_slim vs k_sweep_multi (k <= 20),
 k_sweep_split_slim vs k_sweep_split and k_sweep_multi_split (20 < k <= 40).  Same products, same MFMA sequence per
-column, same epilogue: every output must be bit-identical.  The expanded path is selected by the
-diagnostic switch GPDLA_EXPANDED_RECORDS=1, which the library reads once per process, so it runs in
-a clean child (hot loops: process_qsos.m:185-199, process_qsos_multiple_dlas_meanflux.m:340-381)."""
+column, same epilogue: every output must be bit-identical.  The superseded kernels are not in the
+product library: they live in libgpdla_legacy.so (csrc/gpdla.hip built with -DGPDLA_WITH_LEGACY,
+__graft_entry__.build()), which a clean child process loads through GPDLA_LIB_PATH with the
+diagnostic switch GPDLA_EXPANDED_RECORDS=1 set (hot loops: process_qsos.m:185-199,
+process_qsos_multiple_dlas_meanflux.m:340-381)."""
 import multiprocessing as mp
+import os
 
 import numpy as np
 import pytest
@@ -16,7 +19,9 @@ pytestmark = pytest.mark.gpu
 
 def expanded(kind, k, num_lines, tmp_path, extra_env=None):
     out = tmp_path / f"{kind}_{k}_{num_lines}.npz"
-    env = {"GPDLA_EXPANDED_RECORDS": "1"}
+    from gp_dla_detection_amd import _lib
+    assert os.path.exists(_lib.LEGACY_LIB_PATH), "libgpdla_legacy.so is missing: __graft_entry__.build() makes it"
+    env = {"GPDLA_EXPANDED_RECORDS": "1", "GPDLA_LIB_PATH": _lib.LEGACY_LIB_PATH}
     env.update(extra_env or {})
     pr = mp.get_context("forkserver").Process(target=rcw.run_child, args=(kind, k, num_lines, env, str(out)))
     pr.start()

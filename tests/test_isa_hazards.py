@@ -153,7 +153,7 @@ def test_shipped_hand_issued_memory_operations(shipped_isa, capsys):
     # and the LDS-DMA copies of every sweep / training kernel are followed as well)
     assert sorted(len(gathers[k]) for k in with_gathers) == [12, 24, 36, 48], {k: len(v) for k, v in gathers.items() if v}
     assert all("k_sweep_multi_slim" in k for k in with_gathers)
-    assert sum(1 for v in kernels.values() for i in v[0] if i.asm and i.vmem) > 500
+    assert sum(1 for v in kernels.values() for i in v[0] if i.asm and i.vmem) > 300
     # the hand-written waits of those kernels, and what the instruction stream needs at each (check 3)
     for name in with_gathers:
         nd = int(re.search(r"k_sweep_multi_slimILi(\d)E", name).group(1))

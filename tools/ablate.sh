@@ -7,7 +7,7 @@ set -e
 set -o pipefail
 cd "$(dirname "$0")/.."
 SRC=gp_dla_detection_amd/csrc/gpdla.hip
-FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -Wno-inline-asm"
+FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -Wno-inline-asm -DGPDLA_WITH_LEGACY"
 mkdir -p gpurun_out /tmp/ablate
 : > gpurun_out/ablate.txt
 for v in ${GPDLA_ABLATE_SET:-BASE NOBARRIER NOSLOW "NOSLOW -DGPDLA_ABLATE_NOBARRIER" NOEPI NOVOIGT NOMFMA "NOSLOW -DGPDLA_ABLATE_NOEPI" "NOSLOW -DGPDLA_ABLATE_NOEPI -DGPDLA_ABLATE_NOVOIGT" "NOSLOW -DGPDLA_ABLATE_NOEPI -DGPDLA_ABLATE_NOMFMA"}; do

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostic: the training objective of the library in use (set GPDLA_TRAIN_LEGACY=1 for the
-one-block-per-slot cross-check kernel) against the CPU oracle on two ragged shapes."""
+"""Diagnostic: the training objective of the library in use against the CPU oracle on two ragged shapes.
+For the round-1 one-block-per-slot cross-check kernel:
+    GPDLA_LIB_PATH=gp_dla_detection_amd/csrc/libgpdla_legacy.so GPDLA_TRAIN_LEGACY=1 python tools/check_training_legacy.py
+(the product library does not contain it and reads no environment variable)."""
 import os
 import sys
 

@@ -13,7 +13,7 @@ run() { echo "== $*"; "$@" 2>gpurun_out/${TAG}_configs.err | tail -1 | tee -a $O
 run python3 bench.py --no-cpu-baseline --no-mix-rider                          # config 2 shape, fp64, k = 20
 run python3 bench.py --no-cpu-baseline --workload dr12q-mix                     # DR12Q length mix, 5 % masked
 run python3 bench.py --no-cpu-baseline --k 40 --spectra 256                     # fp64, k = 40 (k_sweep_split_slim)
-GPDLA_EXPANDED_RECORDS=1 run python3 bench.py --no-cpu-baseline --k 40 --spectra 256   # the same on pre-expanded records (k_sweep_split)
+GPDLA_LIB_PATH=$PWD/gp_dla_detection_amd/csrc/libgpdla_legacy.so GPDLA_EXPANDED_RECORDS=1 run python3 bench.py --no-cpu-baseline --k 40 --spectra 256   # the same on pre-expanded records (k_sweep_split)
 run python3 bench.py --no-cpu-baseline --contraction f32                        # config 5 variant, k = 20
 run python3 bench.py --no-cpu-baseline --contraction f32 --k 40 --spectra 256   # config 5: fp32 contraction, k = 40
 run python3 tools/bench_multi.py --spectra 64                                   # config 4: multi-DLA driver, resident

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Diagnostic: time of one training evaluation for several split settings (GPDLA_TRAIN_SPLITS="H,H2,GS").
+# Diagnostic: time of one training evaluation for several split settings (GPDLA_TRAIN_SPLITS="H,H2,GS";
+# the switch exists in libgpdla_legacy.so only -- python -c "from gp_dla_detection_amd import _lib; _lib.build_legacy()").
+export GPDLA_LIB_PATH=$(cd "$(dirname "$0")/.." && pwd)/gp_dla_detection_amd/csrc/libgpdla_legacy.so
 cd "$(dirname "$0")/.."
 K=${1:-20}
 for s in "6,24,24" "5,24,24" "7,24,24" "6,16,24" "6,32,24" "6,48,24" "6,24,16" "6,24,32" "6,24,48" "6,12,12"; do
