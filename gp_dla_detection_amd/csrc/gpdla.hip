@@ -2012,6 +2012,7 @@ TrainDims train_dims(const gpdla_training *t, int k) {
   d.H = 6;    // 79 row blocks x 6 = 474 blocks of 4 waves for 5000 quasars (two per CU)
   d.H2 = 24;  // 20 row blocks x 24 = 480
   d.GS = 24;  // 20 pixel blocks x 24 = 480 blocks of 4 waves (59 KiB of LDS each: two per CU)
+  if (k > 20) d.GS = 24 * kTrWidePB;  // k_train_core_wide: ceil(77 / PB) pixel-group blocks x GS / 4 = 468 blocks at PB = 2
   // (diagnostic: GPDLA_TRAIN_SPLITS="H,H2,GS" overrides the three splits)
 #ifdef GPDLA_WITH_LEGACY
   static const char *splits = std::getenv("GPDLA_TRAIN_SPLITS");
@@ -2110,7 +2111,7 @@ int training_enqueue_mfma(gpdla_training *t, int k, hipStream_t st) {
     if (ly) hipLaunchKernelGGL(k_train_core<true>, core_grid, dim3(256), kTrCoreLds, st, co);
     else hipLaunchKernelGGL(k_train_core<false>, core_grid, dim3(256), kTrCoreLds, st, co);
   } else {
-    const dim3 wide_grid((unsigned)(d.PG * (d.GS / 4)));  // one pixel group per block, four splits (train_dims keeps GS % 4 == 0)
+    const dim3 wide_grid((unsigned)(((d.PG + kTrWidePB - 1) / kTrWidePB) * (d.GS / 4)));  // kTrWidePB pixel groups per block, four splits (train_dims keeps GS % 4 == 0)
     if (ly) hipLaunchKernelGGL(k_train_core_wide<true>, wide_grid, dim3(256), 0, st, co);
     else hipLaunchKernelGGL(k_train_core_wide<false>, wide_grid, dim3(256), 0, st, co);
   }
@@ -2186,6 +2187,9 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
     // the chunk padding behind each tile group of recM / recD is read (never used) by the last chunk copy
     HIP_TRY(hipMemset(t->d_recM, 0, (size_t)groups * (d.T + kTrChunk) * kTrGroupD * sizeof(double)));
     HIP_TRY(hipMemset(t->d_recD, 0, (size_t)groups * (d.TQ + kTrChunk) * kTrGroupD * sizeof(double)));
+    // the columns of the padding tiles (k <= 40: 9 tiles of the last group) are never written by the contractions
+    HIP_TRY(hipMemset(t->d_partB, 0, (size_t)d.NQ16 * d.H * 16 * cols * sizeof(double)));
+    HIP_TRY(hipMemset(t->d_partD, 0, (size_t)d.PG * d.H2 * 16 * cols * sizeof(double)));
     t->ws_ready = true;
     t->ws_class = kc;
   }

@@ -249,8 +249,22 @@ constexpr size_t kTrBuildLds = kTrContractLds + (16 * kTrBuildMaxChunks + kTrMax
 
 // NW: tiles of the block's group that take a_w (compile-time: the A operand of every MFMA is then
 // a fixed register, not a select)
+// NT: tiles of the group that exist at all -- the last group of the k <= 40 class holds 4 w-tiles and 3
+// u-tiles, its other 9 tiles are padding of zeros: no MFMA, no LDS read, no store for them (14 % of a
+// k <= 40 contraction's matrix work; the padded columns of the partial sums are zeroed once, when the
+// workspace is made, and never written).
+template <int NW>
+constexpr int train_group_tiles() {
+  static_assert(TrK<40>::W == 52 && TrK<40>::U == 3 && TrK<20>::W + TrK<20>::U == 16, "tile counts of the two rank classes");
+#ifdef TR_EXP_ALLTILES  // (A/B: the rounds-3/4 form, MFMAs on the padding tiles too)
+  return 16;
+#else
+  return NW == 4 ? 4 + TrK<40>::U : 16;
+#endif
+}
 template <int NW>
 __device__ __forceinline__ void train_contract_body(const TrainContractArgs &a, double *smem, int tg) {
+  constexpr int NT = train_group_tiles<NW>();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bx = blockIdx.x / a.groups;
   const int64_t rb = bx / a.nsplit;
@@ -260,9 +274,9 @@ __device__ __forceinline__ void train_contract_body(const TrainContractArgs &a, 
   constexpr int nw = NW;
   const int64_t t0 = (a.steps * h) / a.nsplit, t1 = (a.steps * (h + 1)) / a.nsplit;  // balanced split
   const int nchunks = (int)((t1 - t0 + kTrChunk - 1) / kTrChunk);
-  d4 acc[16];
+  d4 acc[NT];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < NT; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
   const double *aw = a.Aw + ((active ? r : 0) * a.steps) * 64 + lane, *au = a.Au + ((active ? r : 0) * a.steps) * 64 + lane;
   const double *brec = a.Brec + tg * a.group_stride;
   // whole chunks, copied as per-wave spans (glds_chunk, sweep_kernels.hpp); a chunk that runs past
@@ -307,15 +321,15 @@ __device__ __forceinline__ void train_contract_body(const TrainContractArgs &a, 
 #pragma unroll
     for (int tt = 0; tt < kTrChunk; ++tt) {
       if (tt < csteps) {
-        double b[16];
+        double b[NT];
 #pragma unroll
 #ifdef TR_EXP_NOLDS
-        for (int cc = 0; cc < 16; ++cc) b[cc] = wc[tt] + cc;
+        for (int cc = 0; cc < NT; ++cc) b[cc] = wc[tt] + cc;
 #else
-        for (int cc = 0; cc < 16; ++cc) b[cc] = buf[(size_t)(tt * 16 + cc) * 64];
+        for (int cc = 0; cc < NT; ++cc) b[cc] = buf[(size_t)(tt * 16 + cc) * 64];
 #endif
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc)
+        for (int cc = 0; cc < NT; ++cc)
           acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < nw ? wc[tt] : uc[tt], b[cc], acc[cc], 0, 0, 0);
       }
     }
@@ -329,7 +343,7 @@ __device__ __forceinline__ void train_contract_body(const TrainContractArgs &a, 
   double *o = a.out + ((r * a.nsplit + h) * 16) * (int64_t)a.cols + 256 * tg;
   const int jj = lane >> 4, s = lane & 15;
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
+  for (int c = 0; c < NT; ++c)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) o[(int64_t)(jj + 4 * rr) * a.cols + 16 * c + s] = acc[c][rr];
 }
@@ -372,6 +386,7 @@ struct TrainBuildArgs {
 // LY: the Lyman-series objective (lines.nfl > 1), a compile-time switch so that the plain objective pays nothing for it
 template <int NW, bool LY>
 __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double *smem, int tg) {
+  constexpr int NT = train_group_tiles<NW>();  // (the last group of the k <= 40 class: 7 tiles, see train_contract_body)
   const TrainDims &D = a.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jj = lane >> 4, s = lane & 15;
@@ -384,9 +399,9 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
   const int64_t c0 = (D.PG * h) / D.H, c1 = (D.PG * (h + 1)) / D.H;  // chunks of 16 pixels, balanced split
   const int nchunks = (int)(c1 - c0);
   const TrainScal sc = train_scal(a.x, D.G, D.k);
-  d4 acc[16];
+  d4 acc[NT];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < NT; ++c) acc[c] = d4{0.0, 0.0, 0.0, 0.0};
   const int64_t row = (qreal ? q : 0) * D.ld + 4 * jj + 16 * c0;
   const double2 *pf = reinterpret_cast<const double2 *>(a.flux + row), *pz = reinterpret_cast<const double2 *>(a.log_lya_1pz + row),
                 *pn = reinterpret_cast<const double2 *>(a.noise + row);
@@ -465,11 +480,11 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
       __builtin_amdgcn_sched_barrier(0);
       if (e == 1 && more) load01(c + 1);
       if (e == 3 && more) load23(c + 1);
-      double b[16];
+      double b[NT];
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) b[cc] = buf[(size_t)(e * 16 + cc) * 64];
+      for (int cc = 0; cc < NT; ++cc) b[cc] = buf[(size_t)(e * 16 + cc) * 64];
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc)
+      for (int cc = 0; cc < NT; ++cc)
         acc[cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(cc < NW ? w : u, b[cc], acc[cc], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -483,7 +498,7 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
   // result register rr of tile c: row (lane >> 4) + 4 rr, column 16 (16 tg + c) + (lane & 15)
   double *o = a.out + ((r * D.H + h) * 16) * (int64_t)a.cols + 256 * tg;
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
+  for (int c = 0; c < NT; ++c)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) o[(int64_t)(jj + 4 * rr) * a.cols + 16 * c + s] = acc[c][rr];
   if (tg == 0) {
@@ -1278,27 +1293,36 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
 }
 
 // 20 < k <= 40: 216 column steps -- too many operands for the registers (432 per lane) and 110 KB per
-// quasar group, twice that per block: too many for LDS as well.  A block is ONE pixel group and four
-// consecutive splits of the quasar groups (one per wave): the pixel group's operand -- the same for
-// the four waves -- is staged through LDS in chunks of 12 column steps (6 KiB, double-buffered by
-// the asynchronous copy, one barrier per chunk), each wave's own quasar-group operand comes straight
-// from L2 into registers one chunk ahead (two register sets, the chunk loop unrolled by two), four
-// accumulator chains.  (Round 3 first streamed BOTH operands of every MFMA from L2: 5.3 GB per
-// evaluation through L2, latency-bound at 7.6 TB/s, 0.72-0.78 ms.)  The waves of a block run the same
-// number of chunks -- a split that has one quasar group fewer idles through the last ones.
+// quasar group, twice that per block: too many for LDS as well.  A block is kTrWidePB pixel groups and
+// four consecutive splits of the quasar groups (one per wave): the pixel groups' operands -- the same
+// for the four waves -- are staged through LDS in chunks of 12 column steps (6 KiB per group,
+// double-buffered by the asynchronous copy, one barrier per chunk); each wave's own quasar-group
+// operand comes straight from L2 into registers one chunk ahead (two register sets, the chunk loop
+// unrolled by two) and is used for ALL the block's pixel groups, one accumulator chain each.
+// (Round 3 first streamed BOTH operands of every MFMA from L2: 5.3 GB per evaluation through L2,
+// latency-bound at 7.6 TB/s, 0.72-0.78 ms.  Rounds 3-4 had ONE pixel group per block: the quasar-group
+// operands, 34.6 MB, were then re-read once per pixel group -- 2.65 GB through L2 per launch, 1.17 GB of
+// it from beyond L2 (rocprofv3 FETCH_SIZE, profiles/r05_training_k40_pmc.json) against 0.29 GB of
+// algorithmic traffic, 27 % of the wave cycles waiting: 0.366 ms.  Two pixel groups per block halve
+// that re-read.)  The waves of a block run the same number of chunks -- a split that has one quasar
+// group fewer idles through the last ones.
 constexpr int kTrWideCH = 12;
+#ifndef TR_WIDE_PB
+#define TR_WIDE_PB 2
+#endif
+constexpr int kTrWidePB = TR_WIDE_PB;  // pixel groups per block (TR_WIDE_PB=1: the round-3 form, for A/B)
 template <bool LY>
 __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
   using K = TrC<40>;
-  constexpr int CH = kTrWideCH, NCH = K::Ks / CH;
+  constexpr int CH = kTrWideCH, NCH = K::Ks / CH, PB = kTrWidePB;
   static_assert(K::Ks % CH == 0 && (CH * 64) % 128 == 0 && CH % 4 == 0, "whole chunks of whole KiB");
   static_assert(K::KsW > (NCH - 1) * CH, "only the last chunk mixes X and Y steps");
-  __shared__ __attribute__((aligned(16))) double sB[2][CH * 64];
+  __shared__ __attribute__((aligned(16))) double sB[2][PB][CH * 64];
   __shared__ double T_s[kTrMaxLines + 1], exp_tab[kExpTab];
   if (threadIdx.x < kExpTab) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / kExpTab));  // (published by the first chunk's barrier)
   const TrainDims &D = a.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t pt = blockIdx.x / (D.GS / 4);  // (grid: PG x GS / 4 blocks; GS is a multiple of 4)
+  const int64_t pt0 = (blockIdx.x / (D.GS / 4)) * PB;  // (grid: ceil(PG / PB) x GS / 4 blocks; GS is a multiple of 4)
   const int gs4 = (int)(blockIdx.x % (D.GS / 4)) * 4, gs = gs4 + wave;
   const int64_t g0 = (D.NQ16 * gs) / D.GS, g1 = (D.NQ16 * (gs + 1)) / D.GS;
   int iters = 0;  // block-uniform: the longest of the four splits
@@ -1306,18 +1330,31 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
     iters = max(iters, (int)((D.NQ16 * (gs4 + w + 1)) / D.GS - (D.NQ16 * (gs4 + w)) / D.GS));
   const int total = iters * NCH;
   const int jj = lane >> 4, s = lane & 15;
-  const int64_t p = pt * 16 + s;
   const TrainScal sc = train_scal(a.x, D.G, D.k);
   const double c_0 = sc.c_0, tau_0 = sc.tau_0, beta = sc.beta;
   if (LY && threadIdx.x == 0) train_line_table(a.lines, tau_0, beta, T_s);  // (published by the first chunk's barrier)
-  const double om = p < D.G ? train_omega2(a.x, D.G, D.k, p) : 0.0;
-  const int64_t ob = pt * D.TQ * 64 + lane;
-  const double *bsrc = a.recP + pt * K::Ks * 64;
+  // the block's pixel groups; one behind the last (PG not a multiple of PB) computes on the last one's
+  // operands and stores nothing
+  bool pvalid[PB];
+  int64_t pt[PB], p[PB], ob[PB];
+  double om[PB];
+  const double *bsrc[PB];
+#pragma unroll
+  for (int b = 0; b < PB; ++b) {
+    pvalid[b] = pt0 + b < D.PG;
+    pt[b] = min(pt0 + b, D.PG - 1);
+    p[b] = pt[b] * 16 + s;
+    om[b] = p[b] < D.G ? train_omega2(a.x, D.G, D.k, p[b]) : 0.0;
+    ob[b] = pt[b] * D.TQ * 64 + lane;
+    bsrc[b] = a.recP + pt[b] * K::Ks * 64;
+  }
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const uint32_t sB_lds = __builtin_amdgcn_readfirstlane(lds_address(&sB[0][0]));
-  auto issue = [&](int n) {  // running chunk n: chunk n % NCH of the pixel group's operand into buffer n & 1
-    glds_chunk<CH * 64 / 128, 4>(bsrc + (size_t)(n % NCH) * CH * 64, sB_lds + (uint32_t)(n & 1) * (uint32_t)(CH * 64 * 8), wave_s,
-                                 lane);
+  const uint32_t sB_lds = __builtin_amdgcn_readfirstlane(lds_address(&sB[0][0][0]));
+  auto issue = [&](int n) {  // running chunk n: chunk n % NCH of every pixel group's operand into buffer n & 1
+#pragma unroll
+    for (int b = 0; b < PB; ++b)
+      glds_chunk<CH * 64 / 128, 4>(bsrc[b] + (size_t)(n % NCH) * CH * 64,
+                                   sB_lds + (uint32_t)((n & 1) * PB + b) * (uint32_t)(CH * 64 * 8), wave_s, lane);
   };
   auto group_of = [&](int it) -> int64_t {  // (an idle iteration re-reads the split's last group; nothing of it is used)
     return min(max(min(g0 + it, g1 - 1), (int64_t)0), D.NQ16 - 1);
@@ -1333,48 +1370,59 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
     issue(0);
     load_a(0, A0);
   }
-  double col = 0.0, gc = 0.0, gt = 0.0, gb = 0.0;
-  d4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0, x2 = x0, x3 = x0, yv = x0;
-  TrainCoreRaw raw;
+  double col[PB], gc[PB], gt[PB], gb[PB];
+  d4 xa[PB], yv[PB];  // (one chain per pixel group: PB independent chains alternate on the matrix pipe)
+  TrainCoreRaw raw[PB];
+#pragma unroll
+  for (int b = 0; b < PB; ++b) {
+    col[b] = gc[b] = gt[b] = gb[b] = 0.0;
+    xa[b] = yv[b] = d4{0.0, 0.0, 0.0, 0.0};
+  }
   auto phase = [&](int n, const double (&cur)[CH], double (&nxt)[CH]) {
     const int it = n / NCH, c = n - it * NCH;
     const bool live = g0 + it < g1;
-    glds_wait();      // chunk n of the shared operand landed (this wave's part); so did cur
+    glds_wait();      // chunk n of the shared operands landed (this wave's part); so did cur
     __syncthreads();  // ... everyone's; the other buffer's readers are done
     if (n + 1 < total) {
       issue(n + 1);
       load_a(n + 1, nxt);
     }
     if (c == 0) {
-      x0 = x1 = x2 = x3 = yv = d4{0.0, 0.0, 0.0, 0.0};
-      train_core_load<LY>(a, group_of(it), p, jj, true, raw);  // used behind this group's chunks
+#pragma unroll
+      for (int b = 0; b < PB; ++b) xa[b] = yv[b] = d4{0.0, 0.0, 0.0, 0.0};
     }
-    const double *b = &sB[n & 1][0] + lane;
+    if (c == NCH - 2) {  // the tiles' raw data: one chunk (PB x 12 MFMAs) ahead of their use
+#pragma unroll
+      for (int b = 0; b < PB; ++b) train_core_load<LY>(a, group_of(it), p[b], jj, true, raw[b]);
+    }
+    const double *bl = &sB[n & 1][0][0] + lane;
     if (c < NCH - 1) {
 #pragma unroll
-      for (int j = 0; j < CH; j += 4) {
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], b[j * 64], x0, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j + 1], b[(j + 1) * 64], x1, 0, 0, 0);
-        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j + 2], b[(j + 2) * 64], x2, 0, 0, 0);
-        x3 = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j + 3], b[(j + 3) * 64], x3, 0, 0, 0);
-        if (j % 8 == 4) __builtin_amdgcn_sched_barrier(0);  // (at most eight LDS operands requested ahead: registers)
+      for (int j = 0; j < CH; ++j) {
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+          xa[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], bl[(b * CH + j) * 64], xa[b], 0, 0, 0);
+        if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (at most 4 PB LDS operands requested ahead: registers)
       }
     } else {
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         constexpr int ks0 = (NCH - 1) * CH;
-        if (ks0 + j < K::KsW) {  // compile-time
-          d4 &x = (j & 3) == 0 ? x0 : (j & 3) == 1 ? x1 : (j & 3) == 2 ? x2 : x3;
-          x = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], b[j * 64], x, 0, 0, 0);
-        } else {
-          yv = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], b[j * 64], yv, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+          if (ks0 + j < K::KsW)  // compile-time
+            xa[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], bl[(b * CH + j) * 64], xa[b], 0, 0, 0);
+          else
+            yv[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[j], bl[(b * CH + j) * 64], yv[b], 0, 0, 0);
         }
-        if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+        if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);
       }
       if (live) {
-        const d4 xs = {(x0[0] + x1[0]) + (x2[0] + x3[0]), (x0[1] + x1[1]) + (x2[1] + x3[1]),
-                       (x0[2] + x1[2]) + (x2[2] + x3[2]), (x0[3] + x1[3]) + (x2[3] + x3[3])};
-        train_core_tile<LY>(a, g0 + it, raw, jj, true, ob, om, c_0, tau_0, beta, T_s, exp_tab, xs, yv, col, gc, gt, gb);
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+          train_core_tile<LY>(a, g0 + it, raw[b], jj, pvalid[b], ob[b], om[b], c_0, tau_0, beta, T_s, exp_tab, xa[b], yv[b], col[b],
+                              gc[b], gt[b], gb[b]);
+        }
       }
     }
   };
@@ -1383,7 +1431,9 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
     if (n + 1 < total) phase(n + 1, A1, A0);
   }
   glds_wait();  // (no copy is in flight behind the last chunk; stated for tools/check_vmem_hazard.py)
-  train_core_store(a, pt, gs, lane, col, gc, gt, gb);
+#pragma unroll
+  for (int b = 0; b < PB; ++b)
+    if (pvalid[b]) train_core_store(a, pt[b], gs, lane, col[b], gc[b], gt[b], gb[b]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1413,7 +1463,8 @@ __global__ __launch_bounds__(256) void k_train_finish(TrainFinishArgs a) {
   if ((int64_t)blockIdx.x < G) {
     const int64_t p = blockIdx.x, pt = p >> 4;
     const int ps = (int)(p & 15);
-    for (int e = tid; e < K::Cols; e += 256) {  // A_p (vech) and C_p: sum of the quasar splits, in order
+    // (only the 16 (W + U) columns that exist: the padding tiles of the last group are never written)
+    for (int e = tid; e < 16 * (K::W + K::U); e += 256) {  // A_p (vech) and C_p: sum of the quasar splits, in order
       const double *pd = a.partD + ((pt * D.H2) * 16 + ps) * (int64_t)K::Cols + e;
       double v = 0.0;
       for (int h = 0; h < D.H2; ++h) v += pd[(int64_t)h * 16 * K::Cols];
