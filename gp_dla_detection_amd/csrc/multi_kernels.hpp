@@ -52,6 +52,18 @@ struct ProfilesArgs {
 constexpr int kProfTile = 16;   // pixels per transposed store
 constexpr int kProfWaves = 4;   // waves per block (4 x 2 x 64 x 17 doubles of LDS: two blocks per CU)
 
+#ifdef PROF_EXP_RHOTABLE
+// Cost probe (round 5, results WRONG by construction): the three-line wing sum as ONE piecewise
+// polynomial of rho = lambda / (1 + z_DLA) -- the sum depends on lambda and z_DLA only through rho
+// (voigt.c:278-290) -- binned geometrically around the nearest line centre, 16 bins per octave of
+// |rho - lambda_j| from 2^-4 to 2^9 Angstrom on either side of each of the three lines, degree 7:
+// 1248 rows of 8 coefficients (80 KB).  The table holds zeros: the probe measures what the look-up
+// COSTS in k_profiles (index arithmetic, four 16-byte gathers per lane at the addresses a real table
+// would be read at, the local coordinate, Horner) against the 42 instructions of wing_sum3.
+constexpr int kRhoBinsPerSide = 13 * 16;
+__device__ double g_rho_probe[6 * kRhoBinsPerSide * 8];
+#endif
+
 __global__ __launch_bounds__(kProfWaves * 64) void k_profiles(ProfilesArgs a) {
   __shared__ double s_exp[kExpTab];  // 2^(j/64), the table behind exp_table()
   __shared__ double s_out[kProfWaves][2][64][kProfTile + 1];
@@ -78,6 +90,9 @@ __global__ __launch_bounds__(kProfWaves * 64) void k_profiles(ProfilesArgs a) {
     ms[j] = mult[j] * inv_s;
   }
   const double cs = c_light * inv_s;
+#ifdef PROF_EXP_RHOTABLE
+  const double inv1pz = 1.0 / (1 + z_dla);
+#endif
   // (pre-scaled exp, sweep_kernels.hpp)
   const double nscale_a = -a.nhi_samples[i] * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;
   const double nscale_b = -a.lls_nhi_samples[i] * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;
@@ -93,7 +108,31 @@ __global__ __launch_bounds__(kProfWaves * 64) void k_profiles(ProfilesArgs a) {
     double total = 0.0;
     bool near = false;
     if (L == 3) {
+#ifdef PROF_EXP_RHOTABLE
+      const double rho = lamP * inv1pz;  // rest wavelength at the absorber, Angstrom
+      const bool ab = rho > 1120.6962, bc = rho > 999.12955;  // midpoints of Ly-alpha / beta / gamma
+      const double lc = ab ? 1215.6701 : bc ? 1025.7223 : 972.5368;
+      const int lsel = ab ? 0 : bc ? 1 : 2;
+      const double dd = rho - lc, ad = fabs(dd);
+      near = ad < 1.3e-3 * lc;  // |x| < 30: 30 sqrt2 sigma / c of the line's wavelength
+      const uint32_t hi = hi_word(ad);
+      int bin = (int)(hi >> 16) - (1019 << 4);  // exponent and the top four mantissa bits: 16 bins per octave from 2^-4
+      bin = min(max(bin, 0), kRhoBinsPerSide - 1);
+      const int row = (lsel * 2 + (dd < 0.0 ? 1 : 0)) * kRhoBinsPerSide + bin;
+      const double2 *cp = reinterpret_cast<const double2 *>(g_rho_probe + row * 8);
+      const double2 c01 = cp[0], c23 = cp[1], c45 = cp[2], c67 = cp[3];
+      // the position inside the bin, [0, 1): the mantissa bits below the bin's
+      const double tf = __hiloint2double((int)((hi & 0xFFFFu) | 0x3FF00000u), __double2loint(ad)) - 1.0;
+      double t = fma(c67.y, tf, c67.x);
+      t = fma(t, tf, c45.y);
+      t = fma(t, tf, c45.x);
+      t = fma(t, tf, c23.y);
+      t = fma(t, tf, c23.x);
+      t = fma(t, tf, c01.y);
+      total = fma(t, tf, c01.x);
+#else
       total = wing_sum3(lamP, ms[0], ms[1], ms[2], cs, &near);
+#endif
     } else {
       for (int j = 0; j < L; ++j) {
         const double mj = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
