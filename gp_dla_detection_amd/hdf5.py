@@ -583,29 +583,48 @@ class Dataset(_Node):
             out[sel] = block[tuple(slice(0, s.stop - s.start) for s in sel)]
         return out
 
-    def read_slab(self, lo: int, hi: int) -> np.ndarray:
+    def read_slab(self, lo: int, hi: int, axis1: tuple | None = None) -> np.ndarray:
         """Rows ``lo .. hi`` of the first (slowest) HDF5 dimension, touching only the data they need:
         a view of the memory map for contiguous data, the overlapping chunks for chunked data (the
         chunk index is walked once per dataset).  What a streamed copy of a table too large for
-        memory is built from."""
+        memory is built from.  ``axis1 = (lo1, hi1)``: only that range of the SECOND dimension as
+        well (a 3-D table whose first dimension is short -- ``[max_dlas, S, nq]`` -- is streamed by
+        (first index, range of the second) instead of by whole first-dimension rows)."""
         kind, where, cdims = self._layout_info()
         shape, dt = self.shape, self.dtype
         lo, hi = max(0, int(lo)), min(int(hi), shape[0] if shape else 0)
+        lo1, hi1 = 0, (shape[1] if len(shape) > 1 else 0)
+        if axis1 is not None:
+            if len(shape) < 2:
+                raise HDF5Error("axis1 given for a dataset with fewer than two dimensions")
+            lo1, hi1 = max(0, int(axis1[0])), min(int(axis1[1]), shape[1])
         if kind != "chunked":
-            return self.read(memmap=True)[lo:hi]
+            a = self.read(memmap=True)[lo:hi]
+            return a if axis1 is None else a[:, lo1:hi1]
         if not hasattr(self, "_chunk_index"):
             self._chunk_index = []
             self._chunks(where, len(shape), self._chunk_index)
-        out = np.zeros((max(hi - lo, 0),) + tuple(shape[1:]), dtype=dt)
+        second = (max(hi1 - lo1, 0),) if len(shape) > 1 else ()
+        out = np.zeros((max(hi - lo, 0),) + second + tuple(shape[2:]), dtype=dt)
         for offs, csize, cmask, caddr in self._chunk_index:
             if offs[0] >= hi or offs[0] + cdims[0] <= lo:
+                continue
+            if len(shape) > 1 and (offs[1] >= hi1 or offs[1] + cdims[1] <= lo1):
                 continue
             raw = self._decode_chunk(self.file._bytes(caddr, csize), cmask)
             block = np.frombuffer(raw, dtype=dt, count=int(np.prod(cdims))).reshape(cdims)
             a0, a1 = max(offs[0], lo), min(offs[0] + cdims[0], hi, shape[0])
-            rest = tuple(slice(o, min(o + c, s_)) for o, c, s_ in zip(offs[1:], cdims[1:], shape[1:]))
-            out[(slice(a0 - lo, a1 - lo),) + rest] = block[(slice(a0 - offs[0], a1 - offs[0]),)
-                                                           + tuple(slice(0, r.stop - r.start) for r in rest)]
+            src = [slice(a0 - offs[0], a1 - offs[0])]
+            dst = [slice(a0 - lo, a1 - lo)]
+            if len(shape) > 1:
+                b0, b1 = max(offs[1], lo1), min(offs[1] + cdims[1], hi1, shape[1])
+                src.append(slice(b0 - offs[1], b1 - offs[1]))
+                dst.append(slice(b0 - lo1, b1 - lo1))
+            for o, c, s_ in zip(offs[2:], cdims[2:], shape[2:]):
+                stop = min(o + c, s_)
+                src.append(slice(0, stop - o))
+                dst.append(slice(o, stop))
+            out[tuple(dst)] = block[tuple(src)]
         return out
 
     def __getitem__(self, key):
@@ -805,10 +824,13 @@ class FileWriter:
         return parent, leaf
 
     # ---- datasets -------------------------------------------------------------------------------
-    def create_dataset_streamed(self, name: str, shape, dtype, blocks, attrs: dict | None = None) -> Reference:
+    def create_dataset_streamed(self, name: str, shape, dtype, blocks, attrs: dict | None = None,
+                                in_order: bool = False) -> Reference:
         """A contiguous dataset of the given ``shape`` written from ``blocks``, an iterable of
         arrays that are consecutive slabs along axis 0 -- for tables too large to hold a second
-        (transposed) copy of, e.g. the 13 GB ``sample_log_likelihoods_dla`` of a DR12Q run."""
+        (transposed) copy of, e.g. the 13 GB ``sample_log_likelihoods_dla`` of a DR12Q run.
+        ``in_order=True``: the blocks are any consecutive pieces of the dataset's row-major bytes
+        (e.g. ranges of axis 1 within one index of axis 0); only their total size is checked."""
         parent, leaf = self._split(name)
         dt = np.dtype(dtype).newbyteorder("<") if np.dtype(dtype).byteorder == ">" else np.dtype(dtype)
         shape = tuple(int(x) for x in shape)
@@ -817,13 +839,14 @@ class FileWriter:
         daddr, rows = self._pos, 0
         for blk in blocks:
             blk = np.ascontiguousarray(blk, dtype=dt)
-            if blk.shape[1:] != shape[1:]:
+            if not in_order and blk.shape[1:] != shape[1:]:
                 raise HDF5Error(f"block of shape {blk.shape} does not fit dataset shape {shape}")
             blk.tofile(self._f)
-            rows += blk.shape[0]
+            rows += blk.size if in_order else blk.shape[0]
             self._pos += blk.nbytes
-        if rows != shape[0]:
-            raise HDF5Error(f"{name}: blocks delivered {rows} of {shape[0]} slabs")
+        if rows != (int(np.prod(shape)) if in_order else shape[0]):
+            raise HDF5Error(f"{name}: blocks delivered {rows} of {int(np.prod(shape)) if in_order else shape[0]} "
+                            f"{'elements' if in_order else 'slabs'}")
         msgs = [_message(MSG_DATASPACE, _dataspace_message(shape)),
                 _message(MSG_DATATYPE, _dtype_message(dt), flags=1),
                 _message(MSG_FILL, _fill_message(2)),

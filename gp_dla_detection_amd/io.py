@@ -674,13 +674,18 @@ def chunk_filename(directory: str, test_set_name: str, lo: int, hi: int, multi: 
     return f"{directory}/{stem}_{lo:0{width}d}-{hi:0{width}d}.mat"
 
 
+#: largest piece combine_processed_chunks reads / writes at a time
+COMBINE_SLAB_BYTES = 256 << 20
+
+
 def combine_processed_chunks(paths, out_path: str, test_ind=None) -> None:
     """What ``mat_combine`` (CDDF_analysis/sbatch_reunion.py:13-63) does -- every variable whose
     quasar axis has the first chunk's length is concatenated along that axis, everything else is
     taken from the first chunk -- written as a MATLAB ``-v7.3`` file and streamed in slabs of at
     most 256 MB (``Dataset.read_slab``: memory-mapped for contiguous sources, chunk by chunk for the
-    chunked tables the streamed writer produces), so that the 13 GB sample table of a DR12Q run is
-    never held in memory (the reference's script peaks at ~150 GB, sbatch_reunion.py:6-7).  ``test_ind``: the combined run's selection; by default the
+    chunked tables the streamed writer produces; the 3-D tables of the multi-DLA driver,
+    ``[max_dlas, S, nq]``, by (model, range of samples)), so that the 13 GB sample table of a DR12Q
+    run -- 52 GB for four DLA models -- is never held in memory (the reference's script peaks at ~150 GB, sbatch_reunion.py:6-7).  ``test_ind``: the combined run's selection; by default the
     OR of the chunks' own masks (``mat_combine`` keeps the first chunk's, which then selects only
     that chunk's quasars)."""
     paths = list(paths)
@@ -715,16 +720,24 @@ def combine_processed_chunks(paths, out_path: str, test_ind=None) -> None:
                 if len(shape) == 1:
                     w.create_dataset(name, np.concatenate([f[name].read() for f in files]), attrs=attrs)
                     continue
-                # slab by slab along the slowest dimension: contiguous sources are memory-mapped,
-                # chunked ones (what ProcessedStreamWriter writes) are read chunk row by chunk row
+                # slab by slab: contiguous sources are memory-mapped, chunked ones (what
+                # ProcessedStreamWriter writes) are read chunk row by chunk row.  2-D tables [S, nq]
+                # go by ranges of the slowest dimension; 3-D tables [max_dlas, S, nq] -- whose slowest
+                # dimension is the model, one "row" of it 13 GB for a DR12Q run -- by (model, range
+                # of samples): consecutive pieces of the row-major bytes either way, <= 256 MB each
                 sources = [f[name] for f in files]
-                row_bytes = int(np.prod(shape[1:])) * ds.dtype.itemsize
-                step = max(1, (256 << 20) // max(row_bytes, 1))
-                w.create_dataset_streamed(
-                    name, shape, ds.dtype,
-                    (np.concatenate([d.read_slab(i, i + step) for d in sources], axis=-1)
-                     for i in range(0, shape[0], step)),
-                    attrs=attrs)
+                budget = COMBINE_SLAB_BYTES
+                if len(shape) == 2:
+                    row_bytes = shape[1] * ds.dtype.itemsize
+                    step = max(1, budget // max(row_bytes, 1))
+                    blocks = (np.concatenate([d.read_slab(i, i + step) for d in sources], axis=-1)
+                              for i in range(0, shape[0], step))
+                else:
+                    row_bytes = int(np.prod(shape[2:])) * ds.dtype.itemsize
+                    step = max(1, budget // max(row_bytes, 1))
+                    blocks = (np.concatenate([d.read_slab(m_, m_ + 1, axis1=(i, i + step)) for d in sources], axis=-1)
+                              for m_ in range(shape[0]) for i in range(0, shape[1], step))
+                w.create_dataset_streamed(name, shape, ds.dtype, blocks, attrs=attrs, in_order=True)
         finally:
             w.close()
     finally:

@@ -251,6 +251,12 @@ def run(preloaded_file: str, catalog_file: str, learned_file: str, samples_file:
         result = local_work()
     except Exception as e:
         error = e
+    except BaseException:
+        # KeyboardInterrupt / SystemExit in the middle of the pipeline: the partial chunk file must not
+        # survive looking like a finished one.  (The other ranks then leave their all-reduce by the
+        # process-group timeout: an interrupt is not a failure to agree on.)
+        discard_chunk()
+        raise
     try:
         agree_on_failure(error, what="file-to-file run")  # raises on EVERY rank if any rank failed
     except BaseException:

@@ -283,6 +283,10 @@ def test_random_round_trips_hypothesis(tmp_path_factory):
             lo = data.draw(st.integers(0, shape[0]))
             hi = data.draw(st.integers(lo, shape[0] + 2))
             np.testing.assert_array_equal(d.read_slab(lo, hi), arr[lo:hi])  # streamed recombination reads these
+            if len(shape) >= 2:  # ... and, for the 3-D tables of the multi-DLA driver, ranges of the second dimension
+                lo1 = data.draw(st.integers(0, shape[1]))
+                hi1 = data.draw(st.integers(lo1, shape[1] + 2))
+                np.testing.assert_array_equal(d.read_slab(lo, hi, axis1=(lo1, hi1)), arr[lo:hi, lo1:hi1])
             assert d.attrs["note"] == "x" and d.attrs["n"] == 7
             assert f.eof == os.path.getsize(p)
 

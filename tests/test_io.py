@@ -266,3 +266,41 @@ def test_streamed_processed_writer_refuses_misuse(tmp_path):
     w.append(0, tab(0, 8))
     with pytest.raises(ValueError):
         w.finish(res, test_set_name="t")   # 13 quasars never arrived
+
+
+def test_combine_streams_3d_tables_by_model_and_sample_range(tmp_path, monkeypatch):
+    from gp_dla_detection_amd import hdf5
+    """combine_processed_chunks on multi-DLA chunks: the [max_dlas, S, nq] table is read and written in
+    (model, range of samples) pieces -- never a whole 13-GB model row -- and the result equals the
+    concatenation along the quasar axis.  The slab budget is shrunk so that the small table here
+    really goes through several pieces per model."""
+    rng = np.random.default_rng(5)
+    md, S = 3, 37
+    paths, parts = [], []
+    for c, nq in enumerate((5, 9, 2)):
+        sll = rng.standard_normal((md, S, nq))
+        parts.append(sll)
+        p = str(tmp_path / f"chunk{c}.mat")
+        w = hdf5.FileWriter(p, userblock=io.matlab_userblock())
+        w.create_dataset("p_dlas", rng.uniform(size=(1, nq)))
+        w.create_dataset("sample_log_likelihoods_dla", sll, chunks=(1, 8, nq))       # chunked, as the streamed writer leaves it
+        w.create_dataset("sample_log_likelihoods_lls", rng.standard_normal((S, nq)))  # contiguous 2-D
+        w.create_dataset("test_ind", np.zeros((1, 16), dtype=np.uint8))
+        w.close()
+        paths.append(p)
+    calls = []
+    real = hdf5.Dataset.read_slab
+
+    def spy(self, lo, hi, axis1=None):
+        out = real(self, lo, hi, axis1)
+        calls.append((self.shape, out.nbytes))
+        return out
+    monkeypatch.setattr(hdf5.Dataset, "read_slab", spy)
+    monkeypatch.setattr(io, "COMBINE_SLAB_BYTES", 2048)
+    out = str(tmp_path / "combined.mat")
+    io.combine_processed_chunks(paths, out)
+    with hdf5.File(out) as f:
+        np.testing.assert_array_equal(f["sample_log_likelihoods_dla"].read(), np.concatenate(parts, axis=-1))
+        assert f["sample_log_likelihoods_lls"].shape == (S, 16)
+    three_d = [n for shape, n in calls if len(shape) == 3]
+    assert len(three_d) > 3 * md and max(three_d) <= 2048 + 8 * 9 * 8  # pieces of (model, a few sample rows), never a model row
