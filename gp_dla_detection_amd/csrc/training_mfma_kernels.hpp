@@ -470,6 +470,11 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
     __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
     asm volatile("" ::: "memory");
     __syncthreads();  // ... and everyone's; the other buffer's readers are done
+    // (Known cost, measured in the ISA in round 5: the compiler counts only its own loads, so its wait for
+    // this chunk's first raw elements -- vmcnt(2) / vmcnt(0) a few instructions below -- also waits for
+    // the eight copy instructions issued here.  Issuing the copy behind an explicit vmcnt(3) does not
+    // help: the compiler still places its own waits behind the inline assembly.  The cure would be raw
+    // loads in inline assembly with hand-counted waits, as in k_sweep_multi_slim; not done.)
     if (c + 1 < nchunks) issue_chunk(c + 1);
     const double *buf = smem + (size_t)(c & 1) * kTrChunk * kTrGroupD + lane;
     const double *omc = om_s + 16 * c + 4 * jj;
@@ -1368,7 +1373,11 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
   };
   auto load_a = [&](int n, double (&dst)[CH]) {
     const int it = n / NCH, c = n - it * NCH;
+#ifdef TR_EXP_AHOT  // ablation (results wrong by construction): every wave re-reads ONE quasar group's operand -- an L2-hot A stream
+    const double *re = a.recE + (size_t)c * CH * 64 + lane + 0 * it;
+#else
     const double *re = a.recE + group_of(it) * K::Ks * 64 + (size_t)c * CH * 64 + lane;
+#endif
 #pragma unroll
     for (int j = 0; j < CH; ++j) dst[j] = re[j * 64];
   };
@@ -1389,7 +1398,9 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
     const int it = n / NCH, c = n - it * NCH;
     const bool live = g0 + it < g1;
     glds_wait();      // chunk n of the shared operands landed (this wave's part); so did cur
+#ifndef TR_EXP_WIDE_NOBAR  // (ablation: no chunk barrier; results wrong by construction)
     __syncthreads();  // ... everyone's; the other buffer's readers are done
+#endif
     if (n + 1 < total) {
       issue(n + 1);
       load_a(n + 1, nxt);
@@ -1397,10 +1408,6 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
     if (c == 0) {
 #pragma unroll
       for (int b = 0; b < PB; ++b) xa[b] = yv[b] = d4{0.0, 0.0, 0.0, 0.0};
-    }
-    if (c == NCH - 2) {  // the tiles' raw data: one chunk (PB x 12 MFMAs) ahead of their use
-#pragma unroll
-      for (int b = 0; b < PB; ++b) train_core_load<LY>(a, group_of(it), p[b], jj, true, raw[b]);
     }
     const double *bl = &sB[n & 1][0][0] + lane;
     if (c < NCH - 1) {
@@ -1412,6 +1419,15 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
         if (j % 4 == 3) __builtin_amdgcn_sched_barrier(0);  // (at most 4 PB LDS operands requested ahead: registers)
       }
     } else {
+      // The tiles' raw data are requested HERE, in front of the group's last PB x 12 MFMAs, and live only
+      // inside this branch.  Requested a chunk earlier (round-5 first form) their registers were shared
+      // with the LDS operands of the main branch, and the compiler -- which must not overwrite the
+      // destination of a load in flight -- put s_waitcnt vmcnt(0) into the middle of EVERY chunk's MFMAs:
+      // each wave then sat out the latency of the prefetch it had just issued, 18 times per group
+      // (46 % of the wave cycles parked, profiles/r05_training_k40_pmc_after.json).
+#pragma unroll
+      for (int b = 0; b < PB; ++b) train_core_load<LY>(a, group_of(it), p[b], jj, true, raw[b]);
+      __builtin_amdgcn_sched_barrier(0);  // (nothing that waits for these loads may move in front of the MFMAs)
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         constexpr int ks0 = (NCH - 1) * CH;
