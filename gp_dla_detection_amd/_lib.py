@@ -71,6 +71,13 @@ class Spectra(C.Structure):
                 ("log_priors_no_dla", _dp), ("log_priors_dla", _dp), ("log_priors_lls", _dp)]
 
 
+class SpectraCells(C.Structure):
+    """gpdla_spectra_cells: one array per quasar (pointer arrays are passed as void*: uintp NumPy arrays)."""
+    _fields_ = [("num_quasars", C.c_int64), ("num_pixels", _i64p), ("wavelengths", C.c_void_p),
+                ("flux", C.c_void_p), ("noise_variance", C.c_void_p), ("pixel_mask", C.c_void_p),
+                ("z_qsos", _dp), ("log_priors_no_dla", _dp), ("log_priors_dla", _dp), ("log_priors_lls", _dp)]
+
+
 class Config(C.Structure):
     _fields_ = [("min_lambda", C.c_double), ("max_lambda", C.c_double),
                 ("lya_wavelength", C.c_double), ("lyman_limit", C.c_double),
@@ -118,6 +125,10 @@ SYMBOLS = [
     ("gpdla_default_config", None, [C.POINTER(Config)]),
     ("gpdla_process_batch", C.c_int, [C.POINTER(Model), C.POINTER(Samples), C.POINTER(Spectra),
                                       C.POINTER(Config), C.POINTER(Results), C.c_int]),
+    ("gpdla_process_cells", C.c_int, [C.POINTER(Model), C.POINTER(Samples), C.POINTER(SpectraCells),
+                                      C.POINTER(Config), C.POINTER(Results), C.c_int]),
+    ("gpdla_process_cells_multi", C.c_int, [C.POINTER(Model), C.POINTER(Samples), C.POINTER(SpectraCells),
+                                            _u32p, C.POINTER(Config), C.POINTER(ResultsMulti), C.c_int]),
     ("gpdla_default_batch_quasars", C.c_int64, [C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int]),
     ("gpdla_context_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     ("gpdla_context_destroy", None, [C.c_void_p]),

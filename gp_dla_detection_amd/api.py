@@ -569,6 +569,46 @@ def _spectra_struct(csr: dict, lp_no, lp_dla, lp_lls, keep: list) -> "_lib.Spect
         ptr(lp_dla, np.float64, C.c_double), None if lp_lls is None else ptr(lp_lls, np.float64, C.c_double))
 
 
+def _cells_struct(spectra, lp_no, lp_dla, lp_lls, keep: list) -> "_lib.SpectraCells":
+    """gpdla_spectra_cells over a list of per-quasar dicts: pointers to the arrays as they are (an
+    array that is not contiguous float64 -- uint8 / bool for the mask -- is converted, that one only)."""
+    n = len(spectra)
+    ptrs = np.empty((4, n), dtype=np.uintp)
+    npix = np.empty(n, dtype=np.int64)
+    z = np.empty(n, dtype=np.float64)
+    f64, u8, b1 = np.dtype(np.float64), np.dtype(np.uint8), np.dtype(np.bool_)
+    for i, s in enumerate(spectra):
+        w = s["wavelengths"]
+        if not (isinstance(w, np.ndarray) and w.dtype == f64 and w.flags.c_contiguous):
+            w = np.ascontiguousarray(w, dtype=np.float64)
+        npix[i] = w.size
+        z[i] = s["z_qso"]
+        row = [w]
+        for key in ("flux", "noise_variance"):
+            a = s[key]
+            if not (isinstance(a, np.ndarray) and a.dtype == f64 and a.flags.c_contiguous):
+                a = np.ascontiguousarray(a, dtype=np.float64)
+            row.append(a)
+        m = s["pixel_mask"]
+        if not (isinstance(m, np.ndarray) and (m.dtype == u8 or m.dtype == b1) and m.flags.c_contiguous):
+            m = np.ascontiguousarray(m, dtype=np.uint8)
+        row.append(m)
+        if not (row[1].size == row[2].size == row[3].size == w.size):
+            raise _lib.GpdlaError(-1, f"quasar {i}: wavelengths, flux, noise_variance and pixel_mask differ in length")
+        keep.append(row)
+        for j in range(4):
+            ptrs[j, i] = row[j].__array_interface__["data"][0]
+    keep += [ptrs, npix, z]
+
+    def dptr(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        keep.append(a)
+        return a.ctypes.data_as(_dp)
+    return _lib.SpectraCells(n, npix.ctypes.data_as(C.POINTER(C.c_int64)), ptrs[0].ctypes.data, ptrs[1].ctypes.data,
+                             ptrs[2].ctypes.data, ptrs[3].ctypes.data, z.ctypes.data_as(_dp), dptr(lp_no), dptr(lp_dla),
+                             None if lp_lls is None else dptr(lp_lls))
+
+
 def _result_struct(struct_type, out: dict):
     r = struct_type()
     for name, _ in struct_type._fields_:
@@ -584,7 +624,9 @@ def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None
                  log_priors: tuple | None = None, max_quasars_per_batch: int | None = None,
                  pipeline_slots: int = 3, with_samples: bool = True) -> dict:
     """The ``process_qsos`` script (process_qsos.m:4-250) for a list of quasars: a thin caller of
-    ``gpdla_process_batch``, the one-shot C entry a MEX gateway binds.
+    ``gpdla_process_cells`` (a list: one array per quasar, handed over as it is) or
+    ``gpdla_process_batch`` (CSR arrays), the one-shot C entries a MEX gateway binds (INTEGRATION.md
+    section 3).
 
     ``spectra``: list of dicts with ``wavelengths, flux, noise_variance, pixel_mask, z_qso`` (one
     entry of the ``all_*`` cell arrays each, after the ``test_ind`` subset of :56-61), or the CSR
@@ -596,12 +638,15 @@ def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None
     slots: uploads and downloads overlap the sweeps.  Results do not depend on the batching.
     Returns the variables the script saves (:236-244)."""
     p = params or Parameters()
-    csr = spectra if isinstance(spectra, dict) else spectra_to_csr(list(spectra))
-    nq = csr["z_qsos"].size
+    is_csr = isinstance(spectra, dict)
+    if not is_csr:
+        spectra = list(spectra)
+    z_all = spectra["z_qsos"] if is_csr else np.array([float(s_["z_qso"]) for s_ in spectra], dtype=np.float64)
+    nq = z_all.size
     if log_priors is None:
         if prior_catalog is None:
             raise ValueError("need prior_catalog or log_priors")
-        log_priors = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], csr["z_qsos"], p)
+        log_priors = dla_existence_prior(prior_catalog["z_qsos"], prior_catalog["dla_ind"], z_all, p)
     lp_no, lp_dla = (np.ascontiguousarray(x, dtype=np.float64) for x in log_priors)
     S = np.asarray(samples["offset_samples"]).size
     out = Batch.empty_results(nq, S, with_samples) if nq else {}
@@ -612,10 +657,14 @@ def process_qsos(model: dict, samples: dict, spectra, prior_catalog: dict | None
         cfg.max_quasars_per_batch = int(max_quasars_per_batch or 0)
         keep = []
         m, s_ = _model_struct(model, keep), _samples_struct(samples, keep)
-        sp = _spectra_struct(csr, lp_no, lp_dla, None, keep)
         r = _result_struct(_lib.Results, out)
-        _lib.check(lib.gpdla_process_batch(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r),
-                                           int(device)))
+        if is_csr:
+            sp = _spectra_struct(spectra, lp_no, lp_dla, None, keep)
+            rc = lib.gpdla_process_batch(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r), int(device))
+        else:  # one array per quasar, as they are: the library flattens block by block beside the sweeps
+            sp = _cells_struct(spectra, lp_no, lp_dla, None, keep)
+            rc = lib.gpdla_process_cells(C.byref(m), C.byref(s_), C.byref(sp), C.byref(cfg), C.byref(r), int(device))
+        _lib.check(rc)
         out["log_priors_no_dla"][:] = lp_no
         out["log_priors_dla"][:] = lp_dla
     out["num_lines"] = p.num_lines
@@ -671,8 +720,10 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
     p = params or MultiParameters()
     md = p.max_dlas
     S = np.asarray(samples["offset_samples"]).size
-    csr = spectra if isinstance(spectra, dict) else spectra_to_csr(list(spectra))
-    nq = csr["z_qsos"].size
+    is_csr = isinstance(spectra, dict)
+    if not is_csr:
+        spectra = list(spectra)
+    nq = spectra["z_qsos"].size if is_csr else len(spectra)
     lp_no, lp_lls, lp_dla = (np.ascontiguousarray(x, dtype=np.float64) for x in log_priors)
     lp_dla = lp_dla.reshape(nq, md)
     base_ptr = None
@@ -690,10 +741,16 @@ def process_qsos_multiple_dlas_meanflux(model: dict, samples: dict, spectra, log
         cfg.max_quasars_per_batch = int(max_quasars_per_batch or 0)
         keep = []
         m, s_ = _model_struct(model, keep), _samples_struct(samples, keep)
-        sp = _spectra_struct(csr, lp_no, lp_dla, lp_lls, keep)
         r = _result_struct(_lib.ResultsMulti, out)
-        _lib.check(lib.gpdla_process_batch_multi(C.byref(m), C.byref(s_), C.byref(sp), base_ptr, C.byref(cfg),
-                                                 C.byref(r), int(device)))
+        if is_csr:
+            sp = _spectra_struct(spectra, lp_no, lp_dla, lp_lls, keep)
+            rc = lib.gpdla_process_batch_multi(C.byref(m), C.byref(s_), C.byref(sp), base_ptr, C.byref(cfg), C.byref(r),
+                                               int(device))
+        else:
+            sp = _cells_struct(spectra, lp_no, lp_dla, lp_lls, keep)
+            rc = lib.gpdla_process_cells_multi(C.byref(m), C.byref(s_), C.byref(sp), base_ptr, C.byref(cfg), C.byref(r),
+                                               int(device))
+        _lib.check(rc)
         out["log_priors_no_dla"][:] = lp_no
         out["log_priors_lls"][:] = lp_lls
         out["log_priors_dla"][:] = lp_dla

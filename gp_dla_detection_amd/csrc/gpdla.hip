@@ -1697,15 +1697,7 @@ struct BlockPlan {
   std::vector<std::pair<int64_t, int64_t>> blocks;
 };
 
-int plan_blocks(const gpdla_spectra *sp, const gpdla_config &cfg, int k, int64_t S, int multi_models, BlockPlan *plan) {
-  const int64_t nq = sp->num_quasars;
-  if (nq < 1 || !sp->offsets) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
-  int64_t longest = 1;
-  for (int64_t q = 0; q < nq; ++q) {
-    if (sp->offsets[q + 1] < sp->offsets[q])
-      return fail(GPDLA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing (quasar %lld)", (long long)q);
-    longest = std::max(longest, sp->offsets[q + 1] - sp->offsets[q]);
-  }
+int plan_blocks(int64_t nq, int64_t longest, const gpdla_config &cfg, int k, int64_t S, int multi_models, BlockPlan *plan) {
   if (cfg.pipeline_slots < 0 || cfg.max_quasars_per_batch < 0)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "pipeline_slots and max_quasars_per_batch must be >= 0");
   const int slots = cfg.pipeline_slots > 0 ? cfg.pipeline_slots : 3;
@@ -1717,16 +1709,93 @@ int plan_blocks(const gpdla_spectra *sp, const gpdla_config &cfg, int k, int64_t
   return GPDLA_OK;
 }
 
-gpdla_spectra slice_spectra(const gpdla_spectra *sp, int64_t lo, int64_t hi, int md) {
-  gpdla_spectra s = *sp;  // the pixel arrays are indexed through offsets: a block is a pointer shift
-  s.num_quasars = hi - lo;
-  s.offsets = sp->offsets + lo;
-  s.z_qsos = sp->z_qsos + lo;
-  s.log_priors_no_dla = sp->log_priors_no_dla + lo;
-  s.log_priors_dla = sp->log_priors_dla + lo * (md ? md : 1);
-  if (sp->log_priors_lls) s.log_priors_lls = sp->log_priors_lls + lo;
-  return s;
-}
+// Where a one-shot call's spectra come from: CSR arrays (a block is a pointer shift, nothing is
+// copied on the host) or one array per quasar, as preloaded_qsos.mat's cell arrays hold them (a
+// block is flattened into its batch slot's staging vectors by the upload thread, beside the sweeps).
+struct CsrSource {
+  const gpdla_spectra *sp;
+  int md;
+  int validate(int64_t *longest) const {
+    if (sp->num_quasars < 1 || !sp->offsets || !sp->z_qsos || !sp->log_priors_no_dla || !sp->log_priors_dla)
+      return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
+    *longest = 1;
+    for (int64_t q = 0; q < sp->num_quasars; ++q) {
+      if (sp->offsets[q + 1] < sp->offsets[q])
+        return fail(GPDLA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing (quasar %lld)", (long long)q);
+      *longest = std::max(*longest, sp->offsets[q + 1] - sp->offsets[q]);
+    }
+    return GPDLA_OK;
+  }
+  int64_t num_quasars() const { return sp->num_quasars; }
+  int block(int64_t lo, int64_t hi, size_t, gpdla_spectra *out) const {
+    *out = *sp;  // the pixel arrays are indexed through offsets
+    out->num_quasars = hi - lo;
+    out->offsets = sp->offsets + lo;
+    out->z_qsos = sp->z_qsos + lo;
+    out->log_priors_no_dla = sp->log_priors_no_dla + lo;
+    out->log_priors_dla = sp->log_priors_dla + lo * (md ? md : 1);
+    if (sp->log_priors_lls) out->log_priors_lls = sp->log_priors_lls + lo;
+    return GPDLA_OK;
+  }
+};
+
+struct CellSource {
+  const gpdla_spectra_cells *sp;
+  int md;
+  struct Staging {
+    std::vector<int64_t> offsets;
+    std::vector<double> wl, flux, nv;
+    std::vector<uint8_t> mask;
+  };
+  mutable std::vector<Staging> staging;  // one per batch slot; touched by the upload thread only
+  int validate(int64_t *longest) const {
+    if (sp->num_quasars < 1 || !sp->num_pixels || !sp->wavelengths || !sp->flux || !sp->noise_variance || !sp->pixel_mask ||
+        !sp->z_qsos || !sp->log_priors_no_dla || !sp->log_priors_dla)
+      return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
+    *longest = 1;
+    for (int64_t q = 0; q < sp->num_quasars; ++q) {
+      const int64_t n = sp->num_pixels[q];
+      if (n < 0) return fail(GPDLA_ERR_INVALID_ARGUMENT, "num_pixels[%lld] is negative", (long long)q);
+      if (n > 0 && (!sp->wavelengths[q] || !sp->flux[q] || !sp->noise_variance[q] || !sp->pixel_mask[q]))
+        return fail(GPDLA_ERR_INVALID_ARGUMENT, "quasar %lld: null cell", (long long)q);
+      *longest = std::max(*longest, n);
+    }
+    return GPDLA_OK;
+  }
+  int64_t num_quasars() const { return sp->num_quasars; }
+  int block(int64_t lo, int64_t hi, size_t slot, gpdla_spectra *out) const {
+    Staging &st = staging[slot];
+    const size_t nq = (size_t)(hi - lo);
+    st.offsets.resize(nq + 1);
+    st.offsets[0] = 0;
+    for (size_t q = 0; q < nq; ++q) st.offsets[q + 1] = st.offsets[q] + sp->num_pixels[lo + (int64_t)q];
+    const size_t total = (size_t)st.offsets[nq];
+    st.wl.resize(total);
+    st.flux.resize(total);
+    st.nv.resize(total);
+    st.mask.resize(total);
+    for (size_t q = 0; q < nq; ++q) {
+      const size_t at = (size_t)st.offsets[q], n = (size_t)sp->num_pixels[lo + (int64_t)q];
+      if (!n) continue;
+      std::memcpy(st.wl.data() + at, sp->wavelengths[lo + (int64_t)q], n * sizeof(double));
+      std::memcpy(st.flux.data() + at, sp->flux[lo + (int64_t)q], n * sizeof(double));
+      std::memcpy(st.nv.data() + at, sp->noise_variance[lo + (int64_t)q], n * sizeof(double));
+      std::memcpy(st.mask.data() + at, sp->pixel_mask[lo + (int64_t)q], n);
+    }
+    std::memset(out, 0, sizeof *out);
+    out->num_quasars = (int64_t)nq;
+    out->offsets = st.offsets.data();
+    out->wavelengths = st.wl.data();
+    out->flux = st.flux.data();
+    out->noise_variance = st.nv.data();
+    out->pixel_mask = st.mask.data();
+    out->z_qsos = sp->z_qsos + lo;
+    out->log_priors_no_dla = sp->log_priors_no_dla + lo;
+    out->log_priors_dla = sp->log_priors_dla + lo * (md ? md : 1);
+    out->log_priors_lls = sp->log_priors_lls ? sp->log_priors_lls + lo : nullptr;
+    return GPDLA_OK;
+  }
+};
 
 template <typename T>
 T *shifted(T *p, int64_t rows, int64_t width) {
@@ -1749,40 +1818,25 @@ struct OneShot {  // context + batch slots of a one-shot call, released on every
   }
 };
 
-}  // namespace
-
-extern "C" {
-
-int64_t gpdla_default_batch_quasars(int64_t num_quasars, int64_t longest_spectrum, int k, int64_t num_dla_samples,
-                                    int slots, int64_t budget_bytes, int multi_models) {
-  const double budget = budget_bytes > 0 ? (double)budget_bytes : 96.0 * 1073741824.0;
-  const int64_t per_q = batch_bytes_per_quasar(std::max<int64_t>(longest_spectrum, 1), k, num_dla_samples, multi_models);
-  const int64_t cap = std::max<int64_t>(1, (int64_t)(budget / std::max(slots, 1) / (double)per_q));
-  const int64_t want = std::max<int64_t>(128, (num_quasars + 7) / 8);
-  return std::max<int64_t>(1, std::min({cap, want, (int64_t)4096}));
-}
-
-int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
-                        const gpdla_spectra *spectra, const gpdla_config *config,
-                        gpdla_results *results, int device_id) {
-  if (!model || !samples || !spectra || !results)
-    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
-  if (spectra->log_priors_lls)
-    return fail(GPDLA_ERR_INVALID_ARGUMENT, "log_priors_lls given: use gpdla_process_batch_multi");
-  if (!spectra->z_qsos || !spectra->log_priors_no_dla || !spectra->log_priors_dla)
-    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
+// process_qsos.m:88-233 for every quasar of `src`, pipelined (run_host_pipeline)
+template <class Source>
+int one_shot_single(const gpdla_model *model, const gpdla_samples *samples, const Source &src, const gpdla_config *config,
+                    gpdla_results *results, int device_id) {
   gpdla_config cfg;
   gpdla_default_config(&cfg);
   if (config) cfg = *config;
-  BlockPlan plan;
-  int rc = plan_blocks(spectra, cfg, model->k, samples->num_dla_samples, 0, &plan);
+  int64_t longest = 1;
+  int rc = src.validate(&longest);
   if (rc) return rc;
+  BlockPlan plan;
+  if ((rc = plan_blocks(src.num_quasars(), longest, cfg, model->k, samples->num_dla_samples, 0, &plan))) return rc;
   OneShot os;
   if ((rc = os.open(model, samples, cfg, device_id))) return rc;
   os.batches.assign(plan.slots, nullptr);
   const int64_t S = samples->num_dla_samples;
   auto up = [&](size_t i, size_t slot) {
-    const gpdla_spectra sp = slice_spectra(spectra, plan.blocks[i].first, plan.blocks[i].second, 0);
+    gpdla_spectra sp;
+    if (int r = src.block(plan.blocks[i].first, plan.blocks[i].second, slot, &sp)) return r;
     return os.batches[slot] ? gpdla_batch_reload(os.c, os.batches[slot], &sp) : gpdla_batch_upload(os.c, &sp, &os.batches[slot]);
   };
   auto proc = [&](size_t, size_t slot) { return gpdla_batch_process(os.c, os.batches[slot]); };
@@ -1805,33 +1859,31 @@ int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
     r.MAP_log_nhis = shifted(results->MAP_log_nhis, lo, 1);
     return gpdla_batch_download(os.c, os.batches[slot], &r);
   };
-  auto warm = [&] { prefault_pages(results->sample_log_likelihoods_dla, (size_t)spectra->num_quasars * S * sizeof(double)); };
+  auto warm = [&] { prefault_pages(results->sample_log_likelihoods_dla, (size_t)src.num_quasars() * S * sizeof(double)); };
   return run_host_pipeline(plan.blocks.size(), plan.slots, up, proc, down, warm);
 }
 
-int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
-                              const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
-                              const gpdla_config *config, gpdla_results_multi *results,
-                              int device_id) {
-  if (!model || !samples || !spectra || !results)
-    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
-  if (!spectra->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
-  if (!spectra->z_qsos || !spectra->log_priors_no_dla || !spectra->log_priors_dla)
-    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty spectra field");
+// multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-495 for every quasar of `src`, pipelined
+template <class Source>
+int one_shot_multi(const gpdla_model *model, const gpdla_samples *samples, const Source &src, const uint32_t *base_sample_inds,
+                   const gpdla_config *config, gpdla_results_multi *results, int device_id) {
   gpdla_config cfg;
   gpdla_default_config(&cfg);
   if (config) cfg = *config;
   const int md = cfg.max_dlas;
   if (md < 1 || md > 4) return fail(GPDLA_ERR_UNSUPPORTED, "max_dlas = %d outside [1, 4]", md);
-  BlockPlan plan;
-  int rc = plan_blocks(spectra, cfg, model->k, samples->num_dla_samples, md + 1, &plan);
+  int64_t longest = 1;
+  int rc = src.validate(&longest);
   if (rc) return rc;
+  BlockPlan plan;
+  if ((rc = plan_blocks(src.num_quasars(), longest, cfg, model->k, samples->num_dla_samples, md + 1, &plan))) return rc;
   OneShot os;
   if ((rc = os.open(model, samples, cfg, device_id))) return rc;
   os.batches.assign(plan.slots, nullptr);
   const int64_t S = samples->num_dla_samples, nbase_row = (int64_t)(md > 1 ? md - 1 : 0) * S;
   auto up = [&](size_t i, size_t slot) {
-    const gpdla_spectra sp = slice_spectra(spectra, plan.blocks[i].first, plan.blocks[i].second, md);
+    gpdla_spectra sp;
+    if (int r = src.block(plan.blocks[i].first, plan.blocks[i].second, slot, &sp)) return r;
     return os.batches[slot] ? gpdla_batch_reload(os.c, os.batches[slot], &sp) : gpdla_batch_upload(os.c, &sp, &os.batches[slot]);
   };
   auto proc = [&](size_t i, size_t slot) {
@@ -1866,12 +1918,75 @@ int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *sam
     return gpdla_batch_download_multi(os.c, os.batches[slot], &r);
   };
   auto warm = [&] {
-    const size_t nq = (size_t)spectra->num_quasars;
+    const size_t nq = (size_t)src.num_quasars();
     prefault_pages(results->sample_log_likelihoods_dla, nq * md * S * sizeof(double));
     prefault_pages(results->sample_log_likelihoods_lls, nq * S * sizeof(double));
     prefault_pages(results->base_sample_inds, nq * nbase_row * sizeof(uint32_t));
   };
   return run_host_pipeline(plan.blocks.size(), plan.slots, up, proc, down, warm);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gpdla_default_batch_quasars(int64_t num_quasars, int64_t longest_spectrum, int k, int64_t num_dla_samples,
+                                    int slots, int64_t budget_bytes, int multi_models) {
+  const double budget = budget_bytes > 0 ? (double)budget_bytes : 96.0 * 1073741824.0;
+  const int64_t per_q = batch_bytes_per_quasar(std::max<int64_t>(longest_spectrum, 1), k, num_dla_samples, multi_models);
+  const int64_t cap = std::max<int64_t>(1, (int64_t)(budget / std::max(slots, 1) / (double)per_q));
+  const int64_t want = std::max<int64_t>(128, (num_quasars + 7) / 8);
+  return std::max<int64_t>(1, std::min({cap, want, (int64_t)4096}));
+}
+
+int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
+                        const gpdla_spectra *spectra, const gpdla_config *config,
+                        gpdla_results *results, int device_id) {
+  if (!model || !samples || !spectra || !results)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (spectra->log_priors_lls)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "log_priors_lls given: use gpdla_process_batch_multi");
+  return one_shot_single(model, samples, CsrSource{spectra, 0}, config, results, device_id);
+}
+
+int gpdla_process_cells(const gpdla_model *model, const gpdla_samples *samples,
+                        const gpdla_spectra_cells *spectra, const gpdla_config *config,
+                        gpdla_results *results, int device_id) {
+  if (!model || !samples || !spectra || !results)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (spectra->log_priors_lls)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "log_priors_lls given: use gpdla_process_cells_multi");
+  CellSource src{spectra, 0, {}};
+  src.staging.resize(config && config->pipeline_slots > 0 ? (size_t)config->pipeline_slots : 3);
+  return one_shot_single(model, samples, src, config, results, device_id);
+}
+
+int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
+                              const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
+                              const gpdla_config *config, gpdla_results_multi *results,
+                              int device_id) {
+  if (!model || !samples || !spectra || !results)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (!spectra->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
+  gpdla_config cfg;
+  gpdla_default_config(&cfg);
+  if (config) cfg = *config;
+  return one_shot_multi(model, samples, CsrSource{spectra, cfg.max_dlas}, base_sample_inds, config, results, device_id);
+}
+
+int gpdla_process_cells_multi(const gpdla_model *model, const gpdla_samples *samples,
+                              const gpdla_spectra_cells *spectra, const uint32_t *base_sample_inds,
+                              const gpdla_config *config, gpdla_results_multi *results,
+                              int device_id) {
+  if (!model || !samples || !spectra || !results)
+    return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
+  if (!spectra->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
+  gpdla_config cfg;
+  gpdla_default_config(&cfg);
+  if (config) cfg = *config;
+  CellSource src{spectra, cfg.max_dlas, {}};
+  src.staging.resize(cfg.pipeline_slots > 0 ? (size_t)cfg.pipeline_slots : 3);
+  return one_shot_multi(model, samples, src, base_sample_inds, config, results, device_id);
 }
 
 void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {

@@ -187,6 +187,29 @@ int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
                         const gpdla_spectra *spectra, const gpdla_config *config,
                         gpdla_results *results, int device_id);
 
+/* The same loop with the spectra as preloaded_qsos.mat holds them (preload_qsos.m:64-79): ONE ARRAY PER
+ * QUASAR -- the cells of all_wavelengths / all_flux / all_noise_variance / all_pixel_mask (after the
+ * test_ind subset of process_qsos.m:56-61), or a Python list of NumPy arrays.  Nothing is flattened
+ * up front: the library's upload thread copies block i+1 of the cells into the staging vectors of
+ * its batch slot while block i is swept, so the host copy hides behind the sweeps like the PCIe
+ * copies do (host memory beyond the caller's arrays: `slots` blocks of spectra).  pixel_mask cells
+ * are one byte per pixel, nonzero = masked (mxLogical and numpy.bool_ as they are). */
+typedef struct {
+  int64_t num_quasars;
+  const int64_t *num_pixels;              /* [nq] entries of each of the four cells of quasar q */
+  const double *const *wavelengths;       /* [nq] pointers */
+  const double *const *flux;
+  const double *const *noise_variance;
+  const uint8_t *const *pixel_mask;
+  const double *z_qsos;                   /* [nq] */
+  const double *log_priors_no_dla;        /* [nq] */
+  const double *log_priors_dla;           /* [nq]; multi: [nq][max_dlas] */
+  const double *log_priors_lls;           /* multi only, else NULL */
+} gpdla_spectra_cells;
+int gpdla_process_cells(const gpdla_model *model, const gpdla_samples *samples,
+                        const gpdla_spectra_cells *spectra, const gpdla_config *config,
+                        gpdla_results *results, int device_id);
+
 /* Quasars per batch the one-shot entries (and the Python file pipeline) use by default: small enough
  * that `slots` batches of quasars of `longest_spectrum` pixels fit budget_bytes of HBM (0 = 96 GiB)
  * next to the record pool, and that a run has ~8 batches to overlap, at least 128 so that a launch
@@ -294,6 +317,12 @@ typedef struct {
  * them). */
 int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
                               const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
+                              const gpdla_config *config, gpdla_results_multi *results,
+                              int device_id);
+
+/* ... and with one array per quasar (gpdla_spectra_cells, see gpdla_process_cells). */
+int gpdla_process_cells_multi(const gpdla_model *model, const gpdla_samples *samples,
+                              const gpdla_spectra_cells *spectra, const uint32_t *base_sample_inds,
                               const gpdla_config *config, gpdla_results_multi *results,
                               int device_id);
 

@@ -48,6 +48,8 @@
 
 #include "gpdla.h"
 
+#define AT_LEAST_ONE(n) ((n) ? (n) : 1) /* mxMalloc(0) may return NULL */
+
 static const mxArray *need_field(const mxArray *s, const char *arg, const char *name) {
   const mxArray *f;
   if (!mxIsStruct(s)) mexErrMsgIdAndTxt("gpdla:arg", "%s must be a struct", arg);
@@ -116,13 +118,15 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   const mxArray *c_wl, *c_flux, *c_nv, *c_mask, *prior_flags;
   gpdla_model model;
   gpdla_samples samples;
-  gpdla_spectra spectra;
+  gpdla_spectra_cells spectra;
   gpdla_config cfg;
   gpdla_results_multi res;
   mxArray *out[NUM_FIELDS];
   size_t nq, S, G, n_prior, count, q, i, j, total, md, nb;
-  int64_t *offsets;
-  double *wl, *flux, *nv, *lp_no, *lp_lls, *lp_dla, *lp_dla_lib;
+  int64_t *npix;
+  const double **p_wl, **p_flux, **p_nv;
+  const uint8_t **p_mask;
+  double *lp_no, *lp_lls, *lp_dla, *lp_dla_lib;
   double *sll_dla, *ll_dla, *lpost_dla, *post, *map_z, *map_n, *map_i;
   uint32_t *base_lib, *base_in_lib = NULL;
   int32_t *status;
@@ -195,7 +199,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   md = (size_t)cfg.max_dlas;
   nb = md - 1;
 
-  /* ---- the ragged cell arrays of preloaded_qsos.mat -> CSR ---- */
+  /* ---- the ragged cell arrays of preloaded_qsos.mat, handed over cell by cell ---- */
   c_wl = need_field(m_spectra, "spectra", "wavelengths");
   c_flux = need_field(m_spectra, "spectra", "flux");
   c_nv = need_field(m_spectra, "spectra", "noise_variance");
@@ -211,8 +215,15 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (!mxIsUint32(m_base) || mxGetNumberOfElements(m_base) != nq * S * nb)
       mexErrMsgIdAndTxt("gpdla:arg", "base_sample_inds must be uint32 [nq x S x (max_dlas - 1)] (multi :116)");
   }
-  offsets = (int64_t *)mxMalloc((nq + 1) * sizeof(int64_t));
-  offsets[0] = 0;
+  /* No flattening: the library takes one array per quasar (gpdla_spectra_cells) and copies block by block
+   * into its batch slots beside the sweeps.  Logical masks are one byte per pixel and go as they are;
+   * a mask held as doubles is converted here (into one byte buffer, freed below). */
+  npix = (int64_t *)mxMalloc(AT_LEAST_ONE(nq) * sizeof(int64_t));
+  p_wl = (const double **)mxMalloc(AT_LEAST_ONE(nq) * sizeof(double *));
+  p_flux = (const double **)mxMalloc(AT_LEAST_ONE(nq) * sizeof(double *));
+  p_nv = (const double **)mxMalloc(AT_LEAST_ONE(nq) * sizeof(double *));
+  p_mask = (const uint8_t **)mxMalloc(AT_LEAST_ONE(nq) * sizeof(uint8_t *));
+  total = 0;
   for (q = 0; q < nq; ++q) {
     const mxArray *w = mxGetCell(c_wl, q), *fl = mxGetCell(c_flux, q), *v = mxGetCell(c_nv, q), *mk = mxGetCell(c_mask, q);
     size_t n = w ? mxGetNumberOfElements(w) : 0;
@@ -221,26 +232,23 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       mexErrMsgIdAndTxt("gpdla:arg", "quasar %d: the four cells differ in length", (int)(q + 1));
     if (n && (!mxIsDouble(w) || !mxIsDouble(fl) || !mxIsDouble(v) || !(mxIsLogical(mk) || mxIsDouble(mk))))
       mexErrMsgIdAndTxt("gpdla:arg", "quasar %d: double wavelengths / flux / noise_variance and a logical mask", (int)(q + 1));
-    offsets[q + 1] = offsets[q] + (int64_t)n;
+    npix[q] = (int64_t)n;
+    p_wl[q] = n ? mxGetPr(w) : NULL;
+    p_flux[q] = n ? mxGetPr(fl) : NULL;
+    p_nv[q] = n ? mxGetPr(v) : NULL;
+    p_mask[q] = n && mxIsLogical(mk) ? (const uint8_t *)mxGetLogicals(mk) : NULL;
+    if (n && !mxIsLogical(mk)) total += n;
   }
-  total = (size_t)offsets[nq];
-  wl = (double *)mxMalloc(at_least_one(total) * sizeof(double));
-  flux = (double *)mxMalloc(at_least_one(total) * sizeof(double));
-  nv = (double *)mxMalloc(at_least_one(total) * sizeof(double));
-  mask = (uint8_t *)mxMalloc(at_least_one(total));
+  mask = (uint8_t *)mxMalloc(AT_LEAST_ONE(total));
+  total = 0;
   for (q = 0; q < nq; ++q) {
-    size_t at = (size_t)offsets[q], n = (size_t)(offsets[q + 1] - offsets[q]);
     const mxArray *mk = mxGetCell(c_mask, q);
-    if (n == 0) continue;
-    memcpy(wl + at, mxGetPr(mxGetCell(c_wl, q)), n * sizeof(double));
-    memcpy(flux + at, mxGetPr(mxGetCell(c_flux, q)), n * sizeof(double));
-    memcpy(nv + at, mxGetPr(mxGetCell(c_nv, q)), n * sizeof(double));
-    if (mxIsLogical(mk)) {
-      const mxLogical *b = mxGetLogicals(mk);
-      for (i = 0; i < n; ++i) mask[at + i] = b[i] ? 1 : 0;
-    } else {
+    size_t n = (size_t)npix[q];
+    if (n && !mxIsLogical(mk)) {
       const double *b = mxGetPr(mk);
-      for (i = 0; i < n; ++i) mask[at + i] = b[i] != 0.0;
+      for (i = 0; i < n; ++i) mask[total + i] = b[i] != 0.0;
+      p_mask[q] = mask + total;
+      total += n;
     }
   }
 
@@ -306,11 +314,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   }
 
   spectra.num_quasars = (int64_t)nq;
-  spectra.offsets = offsets;
-  spectra.wavelengths = wl;
-  spectra.flux = flux;
-  spectra.noise_variance = nv;
-  spectra.pixel_mask = mask;
+  spectra.num_pixels = npix;
+  spectra.wavelengths = p_wl;
+  spectra.flux = p_flux;
+  spectra.noise_variance = p_nv;
+  spectra.pixel_mask = p_mask;
   spectra.log_priors_no_dla = lp_no;
   spectra.log_priors_dla = lp_dla_lib;
   spectra.log_priors_lls = lp_lls;
@@ -357,7 +365,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   {
     double *sll_lls = (double *)mxMalloc(at_least_one(nq * S) * sizeof(double));
     res.sample_log_likelihoods_lls = sll_lls;
-    rc = nq ? gpdla_process_batch_multi(&model, &samples, &spectra, base_in_lib, &cfg, &res, device_id) : GPDLA_OK;
+    rc = nq ? gpdla_process_cells_multi(&model, &samples, &spectra, base_in_lib, &cfg, &res, device_id) : GPDLA_OK;
     if (rc == GPDLA_OK) {
       double *m = mxGetPr(out[F_SLL_DLA]), *exc = mxGetPr(out[F_EXC]);
       uint32_t *bm = (uint32_t *)mxGetData(out[F_BASE]);
@@ -406,10 +414,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   mxFree(sll_dla);
   mxFree(lp_dla_lib);
   mxFree(mask);
-  mxFree(nv);
-  mxFree(flux);
-  mxFree(wl);
-  mxFree(offsets);
+  mxFree((void *)p_mask);
+  mxFree((void *)p_nv);
+  mxFree((void *)p_flux);
+  mxFree((void *)p_wl);
+  mxFree(npix);
   if (rc != GPDLA_OK) {
     for (f = 0; f < NUM_FIELDS; ++f) mxDestroyArray(out[f]);
     mexErrMsgIdAndTxt("gpdla:process_qsos_multi", "%s", gpdla_last_error());

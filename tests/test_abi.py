@@ -59,12 +59,14 @@ int main(void) {
   printf("sizeof gpdla_model %zu\n", sizeof(gpdla_model));
   printf("sizeof gpdla_samples %zu\n", sizeof(gpdla_samples));
   printf("sizeof gpdla_spectra %zu\n", sizeof(gpdla_spectra));
+  printf("sizeof gpdla_spectra_cells %zu\n", sizeof(gpdla_spectra_cells));
   printf("sizeof gpdla_config %zu\n", sizeof(gpdla_config));
   printf("sizeof gpdla_results %zu\n", sizeof(gpdla_results));
   printf("sizeof gpdla_results_multi %zu\n", sizeof(gpdla_results_multi));
   OFF(gpdla_model, rest_wavelengths); OFF(gpdla_model, log_c_0); OFF(gpdla_model, log_beta);
   OFF(gpdla_samples, lls_nhi_samples);
   OFF(gpdla_spectra, pixel_mask); OFF(gpdla_spectra, log_priors_lls);
+  OFF(gpdla_spectra_cells, num_pixels); OFF(gpdla_spectra_cells, pixel_mask); OFF(gpdla_spectra_cells, log_priors_lls);
   OFF(gpdla_config, width); OFF(gpdla_config, max_dlas); OFF(gpdla_config, min_z_separation);
   OFF(gpdla_config, rng_seed); OFF(gpdla_config, contraction_precision);
   OFF(gpdla_config, multi_profile_bytes); OFF(gpdla_config, record_pool_bytes);
@@ -107,7 +109,7 @@ def test_c_consumer_links_against_the_header(lib, tmp_path):
     res = subprocess.run([str(exe)], capture_output=True, text=True)
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
     seen = dict(line.rsplit(" ", 1) for line in res.stdout.strip().splitlines())
-    mirrors = {"gpdla_model": _lib.Model, "gpdla_samples": _lib.Samples, "gpdla_spectra": _lib.Spectra,
+    mirrors = {"gpdla_model": _lib.Model, "gpdla_samples": _lib.Samples, "gpdla_spectra": _lib.Spectra, "gpdla_spectra_cells": _lib.SpectraCells,
                "gpdla_config": _lib.Config, "gpdla_results": _lib.Results,
                "gpdla_results_multi": _lib.ResultsMulti}
     for cname, mirror in mirrors.items():

@@ -285,3 +285,20 @@ def test_batches_of_one_context_share_the_profile_table(oracle):
     # and against the oracle, once
     r = oracle_multi(oracle, model, samples, C[0], bsi["C"][0], p)
     compare(ref["C"], 0, r, p)
+
+
+def test_cell_and_csr_entries_agree_multi():
+    """gpdla_process_cells_multi vs gpdla_process_batch_multi: bit-equal, with GPU-drawn indices keyed by
+    the quasar's index in the call (so the batching does not change the draws)."""
+    from gp_dla_detection_amd import api
+    p = MultiParameters(max_dlas=3)
+    model = synthetic.make_model(20)
+    samples = synthetic.make_samples(96)
+    spectra = [synthetic.make_spectrum(70 + i, n, model, mask_fraction=0.03) for i, n in enumerate([210, 88, 301, 140, 64])]
+    lp = priors(spectra, p)
+    want = gp.process_qsos_multiple_dlas_meanflux(model, samples, api.spectra_to_csr(spectra), lp, params=p)
+    for per_batch in (None, 2):
+        got = gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=p, max_quasars_per_batch=per_batch,
+                                                     pipeline_slots=2)
+        for key in want:
+            np.testing.assert_array_equal(want[key], got[key], err_msg=f"{key} {per_batch}")

@@ -426,6 +426,29 @@ def test_chunked_driver_matches_single_batch(model20):
     np.testing.assert_array_equal(one["sample_log_likelihoods_dla"], default["sample_log_likelihoods_dla"])
 
 
+def test_cell_and_csr_entries_agree(model20):
+    """gpdla_process_cells (one array per quasar, flattened block by block inside the library) and
+    gpdla_process_batch (CSR arrays) are the same loop: bit-equal results, whatever the batching;
+    non-contiguous / non-float64 cells and boolean masks are accepted."""
+    samples = synthetic.make_samples(48)
+    spectra = [synthetic.make_spectrum(900 + i, n, model20, mask_fraction=0.04)
+               for i, n in enumerate([130, 77, 412, 0, 256, 9, 333])]
+    spectra[3] = dict(wavelengths=np.zeros(0), flux=np.zeros(0), noise_variance=np.zeros(0),
+                      pixel_mask=np.zeros(0, dtype=bool), z_qso=2.5)             # an empty cell stays NaN
+    spectra[1] = dict(spectra[1], flux=np.asarray(spectra[1]["flux"], dtype=np.float32).astype(np.float64)[::1],
+                      pixel_mask=np.asarray(spectra[1]["pixel_mask"]).astype(bool))
+    spectra[4] = dict(spectra[4], wavelengths=np.repeat(spectra[4]["wavelengths"], 2)[::2])  # a strided view
+    lp = flat_priors(len(spectra))
+    from gp_dla_detection_amd import api
+    csr = api.spectra_to_csr(spectra)
+    want = gp.process_qsos(model20, samples, csr, log_priors=lp)
+    for per_batch, slots in ((None, 3), (2, 2), (3, 1)):
+        got = gp.process_qsos(model20, samples, spectra, log_priors=lp, max_quasars_per_batch=per_batch, pipeline_slots=slots)
+        for key in want:
+            np.testing.assert_array_equal(want[key], got[key], err_msg=f"{key} {per_batch} {slots}")
+    assert np.isnan(want["log_likelihoods_dla"][3]) and want["status"][3] == 1
+
+
 def test_record_pool_groups_do_not_change_results(model20):
     """A batch whose K-step records exceed Parameters.record_pool_bytes is swept group by group
     through one pool (records built, swept, next group): identical results for every record class

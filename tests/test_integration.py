@@ -15,46 +15,7 @@ GATEWAY = os.path.join(ROOT, "integration", "process_qsos_gpdla_mex.c")
 GATEWAY_MULTI = os.path.join(ROOT, "integration", "process_qsos_multi_gpdla_mex.c")
 
 # The MATLAB C Matrix / MEX API as documented (R2018a+ signatures; mwSize = size_t, mwIndex = size_t)
-MEX_H = r"""
-#ifndef TEST_MEX_H
-#define TEST_MEX_H
-#include <stddef.h>
-#include <stdbool.h>
-typedef struct mxArray_tag mxArray;
-typedef size_t mwSize;
-typedef size_t mwIndex;
-typedef bool mxLogical;
-typedef enum { mxREAL, mxCOMPLEX } mxComplexity;
-typedef enum { mxUNKNOWN_CLASS, mxCELL_CLASS, mxSTRUCT_CLASS, mxLOGICAL_CLASS, mxCHAR_CLASS, mxVOID_CLASS,
-               mxDOUBLE_CLASS, mxSINGLE_CLASS, mxINT8_CLASS, mxUINT8_CLASS, mxINT16_CLASS, mxUINT16_CLASS,
-               mxINT32_CLASS, mxUINT32_CLASS, mxINT64_CLASS, mxUINT64_CLASS, mxFUNCTION_CLASS } mxClassID;
-bool mxIsUint32(const mxArray *pa);
-void *mxGetData(const mxArray *pa);
-mxArray *mxCreateNumericArray(mwSize ndim, const mwSize *dims, mxClassID classid, mxComplexity flag);
-bool mxIsStruct(const mxArray *pa);
-bool mxIsCell(const mxArray *pa);
-bool mxIsDouble(const mxArray *pa);
-bool mxIsLogical(const mxArray *pa);
-bool mxIsComplex(const mxArray *pa);
-mxArray *mxGetField(const mxArray *pa, mwIndex index, const char *fieldname);
-mxArray *mxGetCell(const mxArray *pa, mwIndex index);
-double *mxGetPr(const mxArray *pa);
-mxLogical *mxGetLogicals(const mxArray *pa);
-double mxGetScalar(const mxArray *pa);
-double mxGetNaN(void);
-size_t mxGetNumberOfElements(const mxArray *pa);
-size_t mxGetM(const mxArray *pa);
-size_t mxGetN(const mxArray *pa);
-mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
-mxArray *mxCreateStructMatrix(mwSize m, mwSize n, int nfields, const char **fieldnames);
-void mxSetFieldByNumber(mxArray *pa, mwIndex index, int fieldnumber, mxArray *value);
-void mxDestroyArray(mxArray *pa);
-void *mxMalloc(size_t n);
-void mxFree(void *ptr);
-void mexErrMsgIdAndTxt(const char *identifier, const char *err_msg, ...);
-void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);
-#endif
-"""
+MEX_H = open(os.path.join(ROOT, "tests", "mex_mock", "mex.h")).read()
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="no C compiler")
@@ -70,7 +31,7 @@ def test_process_qsos_gateway_compiles_against_the_header(tmp_path):
     undefined = set(re.findall(r"\bU (\w+)", subprocess.run(["nm", str(obj)], capture_output=True, text=True).stdout))
     declared = set(re.findall(r"\b(mx\w+|mex\w+)\(", MEX_H))
     ours = {u for u in undefined if u.startswith("gpdla_")}
-    assert ours == {"gpdla_process_batch", "gpdla_default_config", "gpdla_last_error"}
+    assert ours == {"gpdla_process_cells", "gpdla_default_config", "gpdla_last_error"}
     assert {u for u in undefined if u.startswith(("mx", "mex"))} <= declared
     assert undefined - ours - declared <= {"log", "memcpy", "memset", "_GLOBAL_OFFSET_TABLE_", "__stack_chk_fail"}
 
@@ -89,7 +50,7 @@ def test_multi_dla_gateway_compiles_against_the_header(tmp_path):
     undefined = set(re.findall(r"\bU (\w+)", subprocess.run(["nm", str(obj)], capture_output=True, text=True).stdout))
     declared = set(re.findall(r"\b(mx\w+|mex\w+)\(", MEX_H))
     ours = {u for u in undefined if u.startswith("gpdla_")}
-    assert ours == {"gpdla_process_batch_multi", "gpdla_default_config", "gpdla_last_error"}
+    assert ours == {"gpdla_process_cells_multi", "gpdla_default_config", "gpdla_last_error"}
     assert {u for u in undefined if u.startswith(("mx", "mex"))} <= declared
     assert undefined - ours - declared <= {"log", "pow", "memcpy", "memset", "_GLOBAL_OFFSET_TABLE_", "__stack_chk_fail"}
 
