@@ -156,7 +156,7 @@ def test_multi_dla_gateway_returns_what_the_python_surface_returns(tmp_path):
     p = MultiParameters(max_dlas=3)
     model = synthetic.make_model(20)
     samples = synthetic.make_samples(56)
-    spectra = [synthetic.make_spectrum(400 + i, n, model, mask_fraction=0.04) for i, n in enumerate([180, 77, 260, 0])]
+    spectra = [synthetic.make_spectrum(400 + i, n, model, mask_fraction=0.04) for i, n in enumerate([180, 77, 260, 50])]
     spectra[3] = dict(wavelengths=np.zeros(0), flux=np.zeros(0), noise_variance=np.zeros(0),
                       pixel_mask=np.zeros(0, dtype=bool), z_qso=2.7)   # an empty spectrum: all_exceptions
     cat = synthetic.make_prior_catalog()
