@@ -2127,7 +2127,15 @@ TrainDims train_dims(const gpdla_training *t, int k) {
   d.H = 6;    // 79 row blocks x 6 = 474 blocks of 4 waves for 5000 quasars (two per CU)
   d.H2 = 24;  // 20 row blocks x 24 = 480
   d.GS = 24;  // 20 pixel blocks x 24 = 480 blocks of 4 waves (59 KiB of LDS each: two per CU)
-  if (k > 20) d.GS = 24 * kTrWidePB;  // k_train_core_wide: ceil(77 / PB) pixel-group blocks x GS / 4 = 468 blocks at PB = 2
+  if (k > 20) {
+    d.GS = 24 * kTrWidePB;  // k_train_core_wide: ceil(77 / PB) pixel-group blocks x GS / 4 = 468 blocks at PB = 2
+    // four tile groups make the contraction grids four times larger, so they need fewer splits to fill
+    // the chip -- and every split is a copy of the partial sums through HBM (246 MB at H = 6, 242 MB at
+    // H2 = 24): 79 x 4 x 3 = 948 and 20 x 4 x 12 = 960 blocks.  Measured (tools/train_knobs.sh 40, two
+    // rounds): 6,24 -> 1.122 ms; 3,24 -> 1.075; 6,12 -> 1.077; 3,12 -> 1.03; 3,8 / 3,6 the same; 2,x worse.
+    d.H = 3;
+    d.H2 = 12;
+  }
   // (diagnostic: GPDLA_TRAIN_SPLITS="H,H2,GS" overrides the three splits)
 #ifdef GPDLA_WITH_LEGACY
   static const char *splits = std::getenv("GPDLA_TRAIN_SPLITS");
