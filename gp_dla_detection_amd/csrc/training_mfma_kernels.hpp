@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
       // with the LDS operands of the main branch, and the compiler -- which must not overwrite the
       // destination of a load in flight -- put s_waitcnt vmcnt(0) into the middle of EVERY chunk's MFMAs:
       // each wave then sat out the latency of the prefetch it had just issued, 18 times per group
-      // (46 % of the wave cycles parked, profiles/r05_training_k40_pmc_after.json).
+      // (46 % of the wave cycles parked, profiles/r05_training_k40_pmc.json).
 #pragma unroll
       for (int b = 0; b < PB; ++b) train_core_load<LY>(a, group_of(it), p[b], jj, true, raw[b]);
       __builtin_amdgcn_sched_barrier(0);  // (nothing that waits for these loads may move in front of the MFMAs)
