@@ -50,6 +50,8 @@ def test_headline_line_keeps_its_contract(tmp_path):
     assert d["parity"]["max_abs_delta_vs_oracle"] < 1e-8
     mix = d["config"]["dr12q_mix"]  # the production shape rides along, kernel-timed, never `value`
     assert mix["evals_per_s"] > 0 and 0 < mix["frac"] < 1 and 200 < mix["kept_pixels_mean"] < 1250
+    pc = d["config"]["pcie_c"]  # ... and the PCIe-inclusive rate through the one-shot C entry
+    assert "error" not in pc and pc["evals_per_s"] > 0 and 0 < pc["over_resident"] < 1.5 and "gpdla_process_batch" in pc["what"]
     k40 = d["config"]["k40"]  # ... and the 20 < k <= 40 class
     assert k40["evals_per_s"] > 0 and 0 < k40["frac"] < 1 and "k_sweep_split_slim" in k40["what"]
 
