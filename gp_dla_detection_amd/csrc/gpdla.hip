@@ -1650,7 +1650,7 @@ int run_host_pipeline(size_t nblocks, size_t slots, Up up, Proc proc, Down down,
       ps.raise(GPDLA_ERR_HIP);
     }
   };
-  std::thread uploader([&] {
+  auto upload_stage = [&] {
     guarded([&] {
       for (size_t i = 0; i < nblocks; ++i) {
         if (i >= slots && !ps.wait(ps.downloaded, i - slots)) return;
@@ -1658,8 +1658,8 @@ int run_host_pipeline(size_t nblocks, size_t slots, Up up, Proc proc, Down down,
         ps.set(ps.uploaded, i);
       }
     });
-  });
-  std::thread downloader([&] {
+  };
+  auto download_stage = [&] {
     guarded([&] {
       warm();
       for (size_t i = 0; i < nblocks; ++i) {
@@ -1668,7 +1668,17 @@ int run_host_pipeline(size_t nblocks, size_t slots, Up up, Proc proc, Down down,
         ps.set(ps.downloaded, i);
       }
     });
-  });
+  };
+  // (a thread that cannot be started -- std::system_error -- must not leave the other one running, nor
+  // an exception cross the C boundary: the stages that did start are told to stop and joined)
+  std::thread uploader, downloader;
+  try {
+    uploader = std::thread(upload_stage);
+    downloader = std::thread(download_stage);
+  } catch (const std::exception &e) {
+    fail(GPDLA_ERR_HIP, "host pipeline: cannot start a thread: %s", e.what());
+    ps.raise(GPDLA_ERR_HIP);
+  }
   guarded([&] {
     for (size_t i = 0; i < nblocks; ++i) {
       if (!ps.wait(ps.uploaded, i)) return;
@@ -1676,8 +1686,8 @@ int run_host_pipeline(size_t nblocks, size_t slots, Up up, Proc proc, Down down,
       ps.set(ps.processed, i);
     }
   });
-  uploader.join();
-  downloader.join();
+  if (uploader.joinable()) uploader.join();
+  if (downloader.joinable()) downloader.join();
   if (ps.err) return fail(ps.err, "%s", ps.msg.c_str());
   return GPDLA_OK;
 }

@@ -426,6 +426,37 @@ def test_chunked_driver_matches_single_batch(model20):
     np.testing.assert_array_equal(one["sample_log_likelihoods_dla"], default["sample_log_likelihoods_dla"])
 
 
+def test_one_shot_pipeline_many_small_blocks(model20):
+    """The library's three host stages over 150 one-quasar blocks and over blocks of 7 through 2 slots
+    (every hand-off between the upload thread, the caller's thread and the download thread, a few
+    hundred times): bit-equal to one batch, nothing lost or duplicated; and a block that fails in the
+    middle (a model with more columns than the uploaded priors allow cannot be provoked here, so: an
+    out-of-range replayed index of the multi-DLA driver) stops all three stages with the library's
+    message."""
+    samples = synthetic.make_samples(16)
+    rng = np.random.default_rng(11)
+    spectra = [synthetic.make_spectrum(1200 + i, int(rng.integers(20, 90)), model20, mask_fraction=0.02) for i in range(150)]
+    lp = flat_priors(len(spectra))
+    one = gp.process_qsos(model20, samples, spectra, log_priors=lp, max_quasars_per_batch=len(spectra))
+    for per_batch, slots in ((1, 3), (7, 2), (1, 1)):
+        many = gp.process_qsos(model20, samples, spectra, log_priors=lp, max_quasars_per_batch=per_batch, pipeline_slots=slots)
+        for key in one:
+            np.testing.assert_array_equal(one[key], many[key], err_msg=f"{key} {per_batch} {slots}")
+    from gp_dla_detection_amd.parameters import MultiParameters
+    p = MultiParameters(max_dlas=2)
+    msamples = synthetic.make_samples(16)
+    few = spectra[:12]
+    z = np.array([s["z_qso"] for s in few])
+    cat = synthetic.make_prior_catalog()
+    mlp = gp.dla_existence_prior_multi(cat["z_qsos"], cat["dla_ind"], z, 0.3, 0.7, p)
+    base = np.ones((12, 1, 16), dtype=np.uint32)
+    base[7, 0, 3] = 99  # > S: rejected when block 7 is launched, after blocks 0..6 went through
+    with pytest.raises(Exception) as err:
+        gp.process_qsos_multiple_dlas_meanflux(model20, msamples, few, mlp, params=p, base_sample_inds=base,
+                                               max_quasars_per_batch=1, pipeline_slots=3)
+    assert "exceeds num_dla_samples" in str(err.value)
+
+
 def test_cell_and_csr_entries_agree(model20):
     """gpdla_process_cells (one array per quasar, flattened block by block inside the library) and
     gpdla_process_batch (CSR arrays) are the same loop: bit-equal results, whatever the batching;
