@@ -466,16 +466,20 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
     esum += ex;
   };
   for (int c = 0; c < nchunks; ++c) {
+#ifdef TR_EXP_BUILD_EARLYCOPY  // (A/B: rounds 3-4, the next chunk's copy issued at the top of the chunk)
     // chunk c landed (this wave's part): its copy is older than the (at most six) raw loads in flight
     __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
     asm volatile("" ::: "memory");
     __syncthreads();  // ... and everyone's; the other buffer's readers are done
-    // (Known cost, measured in the ISA in round 5: the compiler counts only its own loads, so its wait for
-    // this chunk's first raw elements -- vmcnt(2) / vmcnt(0) a few instructions below -- also waits for
-    // the eight copy instructions issued here.  Issuing the copy behind an explicit vmcnt(3) does not
-    // help: the compiler still places its own waits behind the inline assembly.  The cure would be raw
-    // loads in inline assembly with hand-counted waits, as in k_sweep_multi_slim; not done.)
     if (c + 1 < nchunks) issue_chunk(c + 1);
+#else
+    // chunk c landed (this wave's part): its copy was issued in the MIDDLE of the previous chunk, behind
+    // that chunk's requests for this chunk's first two pixels and in front of those for the last two
+    // (three loads): only those may still be in flight
+    __builtin_amdgcn_s_waitcnt(0x0F73);  // vmcnt(3)
+    asm volatile("" ::: "memory");
+    __syncthreads();  // ... and everyone's; the other buffer's readers are done
+#endif
     const double *buf = smem + (size_t)(c & 1) * kTrChunk * kTrGroupD + lane;
     const double *omc = om_s + 16 * c + 4 * jj;
     const bool more = c + 1 < nchunks;
@@ -487,7 +491,21 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
       double w, u;
       if (e == 0) element(f01.x, z01.x, n01.x, omc[0], nl_cur & 0xFF, w, u);
       if (e == 1) element(f01.y, z01.y, n01.y, omc[1], (nl_cur >> 8) & 0xFF, w, u);
-      if (e == 2) element(f23.x, z23.x, n23.x, omc[2], (nl_cur >> 16) & 0xFF, w, u);
+      if (e == 2) {
+        element(f23.x, z23.x, n23.x, omc[2], (nl_cur >> 16) & 0xFF, w, u);
+#ifndef TR_EXP_BUILD_EARLYCOPY
+        // The next chunk's record copy is issued HERE: behind the compiler's waits for this chunk's raw
+        // values.  The compiler counts only its own loads, so with the inline-assembly copy issued at
+        // the top of the chunk (rounds 3-4) its vmcnt(2) / vmcnt(0) in front of element 0 also waited
+        // for the eight copy instructions just issued: every wave sat out the latency of its prefetch
+        // once per chunk.  Two K-steps (32 MFMAs of this wave) remain to cover the copy.  k_train_build
+        // 281 -> 275 us at k = 40, 88 -> 85 at k = 20 (profiles/r05_ab_training_k40.txt).  (Forming both
+        // elements of a half together, so that the next chunk's raw loads go out two K-steps earlier,
+        // was measured as well: no gain, 281 us.)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue_chunk(c + 1);
+#endif
+      }
       if (e == 3) element(f23.y, z23.y, n23.y, omc[3], nl_cur >> 24, w, u);
       __builtin_amdgcn_sched_barrier(0);
       if (e == 1 && more) load01(c + 1);
