@@ -524,6 +524,7 @@ __device__ __forceinline__ void train_build_body(const TrainBuildArgs &a, double
       esum += ex;
     }
   }
+  glds_wait();  // (no copy is in flight behind the last chunk; stated for tools/check_vmem_hazard.py)
   if (!active) return;
   // result register rr of tile c: row (lane >> 4) + 4 rr, column 16 (16 tg + c) + (lane & 15)
   double *o = a.out + ((r * D.H + h) * 16) * (int64_t)a.cols + 256 * tg;
