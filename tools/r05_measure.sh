@@ -11,6 +11,8 @@ mkdir -p gpurun_out/profiles
 case $PART in
   headline)
     bash tools/profile.sh r05 configs1 > gpurun_out/r05_profile.log 2>&1 && echo "headline profile ok"
+    # bench.py reports roofline.traffic only from a PMC summary of the library it loads: hand it this one
+    cp gpurun_out/profiles/r05_pmc.json profiles/pmc_latest.json
     python bench.py --steps 20 --warmup 5 > gpurun_out/profiles/r05_bench_final.json 2> gpurun_out/r05_bench_final.err && echo "bench ok"
     python bench.py --pcie --pcie-c --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/profiles/r05_bench_pcie.json 2> gpurun_out/r05_bench_pcie.err && echo "pcie ok"
     ;;
