@@ -77,8 +77,8 @@ def pmc_traffic(args):
         with open(path) as f:
             p = json.load(f)
         c = p["config"]
-        same = (c.get("workload", "configs1"), c["spectra"], c["k"], c["dla_samples"]) == (
-            args.workload, args.spectra, args.k, args.samples)
+        same = (c.get("workload", "configs1"), c["spectra"], c["k"], c["dla_samples"], c.get("num_lines", 3)) == (
+            args.workload, args.spectra, args.k, args.samples, args.num_lines)
         if same and p.get("lib_sha256") == lib_sha256():
             return float(p["hbm_bytes_per_launch"]), p.get("tag")
     except (OSError, KeyError, ValueError):
@@ -309,6 +309,9 @@ def main():
     ap.add_argument("--contraction", choices=["f64", "f32"], default="f64",
                     help="f32: BASELINE config 5's study variant (fp32 matrix-core contraction, fp64 "
                          "everything else); not parity-grade, reports its max-abs delta vs f64")
+    ap.add_argument("--num-lines", type=int, default=3,
+                    help="Lyman-series members in the Voigt profile (set_parameters.m:63: 3; voigt.c:16 allows 31); "
+                         "a diagnostic: the headline is quoted at 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mix-rider", action="store_true",
                     help="configs1 at N = 1 also times ONE launch of the dr12q-mix shape after the timed "
@@ -393,7 +396,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timeout)
 
     stream = torch.cuda.Stream()
-    params = gp.Parameters(contraction_precision=1 if args.contraction == "f32" else 0)
+    if args.num_lines != 3:  # a diagnostic line: the oracle leg and the riders are quoted at three lines
+        args.no_cpu_baseline = args.no_mix_rider = args.no_pcie_c = True
+    params = gp.Parameters(contraction_precision=1 if args.contraction == "f32" else 0, num_lines=args.num_lines)
     ctx = gp.Context(local_rank, params=params, stream=stream)
     ctx.set_model(model)
     ctx.set_samples(samples)
@@ -505,7 +510,7 @@ def main():
                        "pixels": args.pixels if args.workload == "configs1" else
                        {"kept_min": int(n_kept.min()), "kept_mean": float(n_kept.mean()),
                         "kept_max": int(n_kept.max())},
-                       "k": args.k, "dla_samples": args.samples, "num_lines": 3,
+                       "k": args.k, "dla_samples": args.samples, "num_lines": args.num_lines,
                        "parallelism": f"spectra sharded over {world} GPU(s), "
                                       f"{'gloo (REHEARSAL on one GPU)' if rehearsal else 'RCCL'} all-gather of "
                                       "the 15-column posterior table",

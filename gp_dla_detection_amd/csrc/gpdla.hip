@@ -128,6 +128,7 @@ int ensure_line_table(int device_id) {
     t.y2[i] = t.y[i] * t.y[i];
     t.cwing[i] = lead[i] * t.y[i];
     t.t2[i] = kE2 - 2.0 * t.y2[i];
+    t.wing[i] = {GPDLA_SPEED_OF_LIGHT_CGS / wl[i] / 1e8 / (std::sqrt(2.0) * sigma), t.y2[i], t.cwing[i], 0.0};
   }
   for (int i = 0; i < 7; ++i) t.taps[i] = taps[i];
   t.c = GPDLA_SPEED_OF_LIGHT_CGS;
@@ -745,16 +746,17 @@ int launch_sweep(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   return GPDLA_OK;
 }
 
-// k_sweep_slim: k <= 20, three lines, fp64, slim records
+// k_sweep_slim: k <= 20, fp64, slim records (LINES = 3, or 0: the line count of the configuration)
+template <int LINES>
 int launch_sweep_slim(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
   const size_t lds = (size_t)kSlimLdsDoubles * sizeof(double);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_slim),
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_slim<LINES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   args.blocks_per_quasar = (int32_t)((b->S + 1 + kSweepWaves * kSamplesPerWave - 1) / (kSweepWaves * kSamplesPerWave));
   const int64_t nblocks = 8 * ((b->nq + 7) / 8) * (int64_t)args.blocks_per_quasar;
   if (nblocks > 2147483647LL) return fail(GPDLA_ERR_UNSUPPORTED, "batch too large for one launch");
   if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  hipLaunchKernelGGL(k_sweep_slim, dim3((unsigned)nblocks), dim3(kSweepWaves * 64), lds, c->stream, args);
+  hipLaunchKernelGGL(k_sweep_slim<LINES>, dim3((unsigned)nblocks), dim3(kSweepWaves * 64), lds, c->stream, args);
   HIP_TRY(hipGetLastError());
   if (c->timing) {
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -790,7 +792,7 @@ int launch_sweep_split(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
 // formed in registers)
 template <int LINES>
 int launch_sweep_split_slim(gpdla_context *c, gpdla_batch *b, SweepArgs args) {
-  const size_t loop_doubles = sweep_split_slim_lds_doubles(false, LINES > 0 ? 0 : args.num_lines);
+  const size_t loop_doubles = sweep_split_slim_lds_doubles(false);
   using ES = EpilogueShape<52, 4>;
   const size_t epi_doubles = kExpTab + (size_t)2 * ES::SPP * ES::stride(56);
   const size_t lds = std::max(loop_doubles, epi_doubles) * sizeof(double);
@@ -935,14 +937,15 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   HIP_TRY(hipSetDevice(c->device_id));
   hipStream_t st = c->stream;
   const int num_lines = c->cfg.num_lines;
-  // k <= 20, three lines, fp64: slim step records, vech(m m') formed inside the sweep (k_sweep_slim).
+  // k <= 20, fp64: slim step records, vech(m m') formed inside the sweep (k_sweep_slim; three lines at
+  // compile time, any other count at run time).
   // GPDLA_EXPANDED_RECORDS=1 (diagnostic): the pre-expanded records of k_sweep, for A/B timing.
   GPDLA_LEGACY_SWITCH(expanded, "GPDLA_EXPANDED_RECORDS");
   const bool f32 = c->cfg.contraction_precision == 1;
   // GPDLA_SPLIT_LEGACY=1 (diagnostic): the k_sweep form of 20 < k <= 40 in which every wave of a group
   // repeats the Voigt/weight arithmetic, for A/B timing against k_sweep_split
   GPDLA_LEGACY_SWITCH(legacy, "GPDLA_SPLIT_LEGACY");
-  const bool slim = b->k <= 20 && num_lines == 3 && !f32 && !expanded;
+  const bool slim = b->k <= 20 && !f32 && !expanded;
   // 20 < k <= 40, fp64: slim records as well (k_sweep_split_slim); GPDLA_EXPANDED_RECORDS=1 keeps
   // k_sweep_split on the pre-expanded 29-KiB records
   const bool slim40 = b->k > 20 && !f32 && !expanded && !legacy;
@@ -983,13 +986,13 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
     sa.order = b->d_order + g.first;
     sa.nq = g.second - g.first;
     if (slim) {
-      rc = launch_sweep_slim(c, b, sa);
+      rc = three ? launch_sweep_slim<3>(c, b, sa) : launch_sweep_slim<0>(c, b, sa);
     } else if (b->k <= 20) {  // compact class: 13 w-tiles + 1 u-tile on the matrix cores, 2 + 4 columns on the VALU
-      if (!f32) {
+      if (!f32) {  // (fp64 takes k_sweep_slim above: the pre-expanded fp64 forms are in libgpdla_legacy.so only)
 #ifdef GPDLA_WITH_LEGACY
         rc = three ? launch_sweep<double, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
-#else  // (three lines in fp64 take k_sweep_slim above: the pre-expanded three-line form is in libgpdla_legacy.so only)
-        rc = launch_sweep<double, 8, 14, 1, 4, 13, 0>(c, b, sa);
+#else
+        rc = fail(GPDLA_ERR_UNSUPPORTED, "pre-expanded fp64 records are in libgpdla_legacy.so only");
 #endif
       }
       else rc = three ? launch_sweep<float, 8, 14, 1, 8, 13, 3>(c, b, sa) : launch_sweep<float, 8, 14, 1, 4, 13, 0>(c, b, sa);
@@ -1242,7 +1245,7 @@ int launch_sweep_multi_slim(gpdla_context *c, const SweepMultiArgs &args) {
 template <int ND>
 int launch_sweep_multi_split_slim_nd(gpdla_context *c, SweepMultiArgs args) {
   using ES = EpilogueShape<52, 4>;
-  const size_t lds = std::max(sweep_split_slim_lds_doubles(true, 0), kExpTab + (size_t)2 * ES::SPP * ES::stride(56)) * sizeof(double);
+  const size_t lds = std::max(sweep_split_slim_lds_doubles(true), kExpTab + (size_t)2 * ES::SPP * ES::stride(56)) * sizeof(double);
   if (lds > 160 * 1024) return fail(GPDLA_ERR_UNSUPPORTED, "multi split sweep needs %zu B of LDS", lds);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_split_slim<0, ND, SweepMultiArgs>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

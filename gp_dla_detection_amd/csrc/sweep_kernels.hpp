@@ -80,6 +80,11 @@ struct LineTable {
   double inv_sqrt2_sigma;           // 1/(sqrt2 sigma)
   double inv_sqrt2pi_sigma;         // 1/(sqrt(2 pi) sigma)
   const double *near_poly;          // [31][kNearIntervals][kNearCoef], near_tables.hpp (device memory)
+  // wing tier of a run-time line count, one 32-byte entry per line (one scalar load each):
+  // x_j = lambda / (1 + z) kms_j - c / (sqrt2 sigma) with kms_j = c / (wavelength_j 1e8) / (sqrt2 sigma).
+  struct WingLine {
+    double kms, y2, cwing, pad;
+  } wing[kMaxLines];
 };
 __constant__ LineTable g_lines;
 
@@ -1301,6 +1306,58 @@ __device__ __forceinline__ double total_near(double lamP, double m0, double m1, 
                            : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
       total += f;
     }
+  }
+  return total;
+}
+
+// Wing tier for a line count known at run time only: sqrt(pi) Sum_{j<L} lead_j Re w_j by the wing
+// formula, from rho = lambda / (1 + z_DLA), kLineUnroll lines at a time -- their scalar loads are
+// issued together and their dependent chains (reciprocal, Newton step, degree-5 Horner) interleave;
+// line by line, a wave waited for three scalar loads and one ~20-deep chain per line (measured at 31
+// lines on 200 x 1500 pixels x 10^4 samples: 115 ms one at a time).  *near: some line j < L is
+// within 30 Doppler widths of this lane's pixel (the caller then takes total_near_at).
+constexpr int kLineUnroll = 4;
+__device__ __forceinline__ double wing_sum_runtime(double rho, double cs, int L, bool *near_out) {
+  double total = 0.0;
+  bool near = false;
+  int j0 = 0;
+  for (; j0 + kLineUnroll <= L; j0 += kLineUnroll) {  // whole groups
+    double f[kLineUnroll];
+#pragma unroll
+    for (int u = 0; u < kLineUnroll; ++u) {
+      const double x = fma(rho, g_lines.wing[j0 + u].kms, -cs);
+      const double x2 = x * x;
+      near |= x2 < 900.0;
+      f[u] = wing_core(x2, g_lines.wing[j0 + u].y2);
+    }
+#pragma unroll
+    for (int u = 0; u < kLineUnroll; ++u) total = fma(g_lines.wing[j0 + u].cwing, f[u], total);
+  }
+  for (; j0 < L; ++j0) {  // the last L mod kLineUnroll lines, one at a time (padding the group to
+    // four cost 5 ms of 40 at five lines and of 31 at one)
+    const double x = fma(rho, g_lines.wing[j0].kms, -cs);
+    const double x2 = x * x;
+    near |= x2 < 900.0;
+    total = fma(g_lines.wing[j0].cwing, wing_core(x2, g_lines.wing[j0].y2), total);
+  }
+  *near_out = near;
+  return total;
+}
+
+// The same sum with the reference's multiplier c / (wavelength_j (1 + z)) / 1e8 (voigt.c:278-279) formed
+// here, line by line: for kernels that keep no table of it (k_sweep_slim<0>); two divisions per line,
+// on the rare pixels within 30 Doppler widths of a line only.
+__device__ __forceinline__ double total_near_at(double lamP, double one_plus_z, int L) {
+  const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
+  const double *tab = g_lines.near_poly;
+  double total = 0.0;
+  for (int j = 0; j < L; ++j) {
+    const double mult = c_light / (g_lines.wavelength_cm[j] * one_plus_z) / 1e8;
+    const double ax = fabs((lamP * mult - c_light) * inv_s);  // voigt.c:287
+    const double f = ax < 30.0
+                         ? 1.7724538509055159 * g_lines.leading[j] * near_poly(tab + j * kNearLineDoubles, ax)
+                         : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
+    total += f;
   }
   return total;
 }

@@ -169,7 +169,14 @@ __device__ __forceinline__ double slim_factor_pass(const d4 (&acc)[14], const do
   return factor_rows<ES::ROWS, ES::LPS, 20>(e + half * ncols, s & (ES::LPS - 1), k, voff, q_s, ld_s, n_kept);
 }
 
+// LINES: 3 (set_parameters.m:63, the production value: the three-line wing tier wing_sum3), or 0: the
+// line count is a.num_lines, read at run time (voigt.c:16, 266 default to all 31).  The 160 KiB of LDS
+// are spoken for, so the run-time form keeps no per-sample table of line multipliers: the wing tier
+// takes x_j = (lambda / (1 + z_DLA)) kms_j - c / (sqrt2 sigma) with kms_j from constant memory (scalar
+// loads; wing_sum_runtime), and the rare near tier forms the reference's own multiplier (voigt.c:278-279) on the spot.
+template <int LINES>
 __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
+  static_assert(LINES == 3 || LINES == 0, "three lines at compile time, or a run-time count");
   extern __shared__ double smem[];
   constexpr int WAVES = kSweepWaves, CH = kSlimCH;
   const int64_t xj = blockIdx.x >> 3;
@@ -194,9 +201,13 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
   const int32_t sample = is_sample ? a.perm[slot] : 0;
   const double z_dla = m.min_z_dla + (m.max_z_dla - m.min_z_dla) * a.offset_samples[sample];  // process_qsos.m:162-164
   const double nhi = a.nhi_samples[sample];
-  double mult_r[3];
+  [[maybe_unused]] double mult_r[3];
+  [[maybe_unused]] const double opz = 1 + z_dla, inv_opz = 1.0 / opz;
+  [[maybe_unused]] const int L = LINES > 0 ? LINES : a.num_lines;
+  if constexpr (LINES == 3) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) mult_r[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;  // voigt.c:278-279
+    for (int j = 0; j < 3; ++j) mult_r[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;  // voigt.c:278-279
+  }
   if (tid < kExpTab) ring[tid * kRing2 + 32] = exp2((double)tid * (1.0 / kExpTab));
   double *my_ring = ring + (size_t)(wave * kSamplesPerWave + s) * kRing2 + jj;
   const double *lam = a.lam_pad + m.lam_off;
@@ -266,18 +277,32 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
   issue_chunk(0);
 
   const double c_light = g_lines.c, inv_s = g_lines.inv_sqrt2_sigma;
-  double ms_r[3];
+  [[maybe_unused]] double ms_r[3];
+  if constexpr (LINES == 3) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) ms_r[j] = mult_r[j] * inv_s;
+    for (int j = 0; j < 3; ++j) ms_r[j] = mult_r[j] * inv_s;
+  }
   const double cs = c_light * inv_s;
+  // sqrt(pi) Sum_j lead_j Re w_j at one padded pixel: voigt.c:282-289
+  auto optical_sum = [&](double lamP) -> double {
+    if constexpr (LINES == 3) {
+      bool near;
+      double total = wing_sum3(lamP, ms_r[0], ms_r[1], ms_r[2], cs, &near);
+      if (__builtin_expect(__any(near), 0)) total = total_near<3>(lamP, mult_r[0], mult_r[1], mult_r[2], nullptr, 3);
+      return total;
+    } else {
+      bool near;
+      double total = wing_sum_runtime(lamP * inv_opz, cs, L, &near);
+      if (__builtin_expect(__any(near), 0)) total = total_near_at(lamP, opz, L);
+      return total;
+    }
+  };
 
   __syncthreads();  // the exp table visible
   // prime the ring with padded pixels 0..11 (the raw profile runs three K-steps ahead)
   for (int c3 = 0; c3 < 3; ++c3) {
     const double lam0 = lam[min(4 * c3 + jj, n_pad - 1)];
-    bool near0;
-    double tot = wing_sum3(lam0, ms_r[0], ms_r[1], ms_r[2], cs, &near0);
-    if (__any(near0)) tot = total_near<3>(lam0, mult_r[0], mult_r[1], mult_r[2], nullptr, 3);
+    const double tot = optical_sum(lam0);
     const ExpState es0 = exp_ring_begin_scaled(nscale64 * tot, exp_pad);
     const double v = exp_table_end_scaled(es0);
     my_ring[4 * c3] = v;
@@ -341,9 +366,7 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
         const double py = p01.x, pmu = p01.y, pom = p23.x, pnu = p23.y;
         __builtin_amdgcn_sched_barrier(0);
         // (1) raw profile three K-steps ahead: voigt.c:282-292
-        bool near;
-        double total = wing_sum3(lamP, ms_r[0], ms_r[1], ms_r[2], cs, &near);
-        if (__builtin_expect(__any(near), 0)) total = total_near<3>(lamP, mult_r[0], mult_r[1], mult_r[2], nullptr, 3);
+        const double total = optical_sum(lamP);
         const ExpState es = exp_ring_begin_scaled(nscale64 * total, exp_pad);
         __builtin_amdgcn_sched_barrier(0);
         double bop[14];

@@ -141,12 +141,11 @@ __global__ __launch_bounds__(256) void k_build_slim40_records(BuildRecordsArgs a
 }
 
 // LDS doubles of the loop phase (the epilogue reuses the array from the stage buffers on)
-__host__ __device__ constexpr size_t sweep_split_slim_lds_doubles(bool multi, int num_lines_runtime) {
+__host__ __device__ constexpr size_t sweep_split_slim_lds_doubles(bool multi) {
   return kExpTab + 2 * (size_t)kS40CH * kS40Rec      // exp table | two chunks of raw records
          + 2 * 2 * 2 * (size_t)kS40CH * 64           // (w, u): parity x group x {w, u} x step x lane
          + 2 * 4 * 2 * 16                            // per-role partial sums at the end
-         + (multi ? 0 : 2 * 16 * (size_t)kS40Ring)   // raw ring per group
-         + (size_t)2 * 16 * num_lines_runtime;       // per-sample line multipliers (run-time line count)
+         + (multi ? 0 : 2 * 16 * (size_t)kS40Ring);  // raw ring per group
 }
 
 // LINES: number of Lyman lines when known at compile time (0: read at run time); single-DLA only.
@@ -185,7 +184,6 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
   double *wu = stage + (size_t)2 * CH * kS40Rec;            // [2 parity][2 groups][2][CH][64]
   double *red = wu + 2 * 2 * 2 * CH * 64;                   // [2 groups][4 roles][2][16]
   double *ring = red + 2 * 4 * 2 * 16;                      // [2 groups][16][kS40Ring]   (single-DLA)
-  double *mult_s = ring + (kMulti ? 0 : 2 * 16 * kS40Ring); // [2*16][L] (run-time L only)
 
   const int64_t slot0 = (int64_t)bq * (2 * kSamplesPerWave) + group * kSamplesPerWave;
   const int64_t slot = slot0 + s;
@@ -202,7 +200,8 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
   [[maybe_unused]] int L = 0;
   [[maybe_unused]] double nscale64 = 0.0, cs = 0.0, inv_s = 0.0;
   [[maybe_unused]] double mult_r[LINES > 0 ? LINES : 1], ms_r[LINES > 0 ? LINES : 1];
-  [[maybe_unused]] double *my_mult = nullptr, *my_ring = nullptr;
+  [[maybe_unused]] double *my_ring = nullptr;
+  [[maybe_unused]] double opz = 1.0, inv_opz = 1.0;  // run-time line count: 1 + z_DLA and its reciprocal (wing_sum_runtime)
   [[maybe_unused]] const double *lam = nullptr;
   [[maybe_unused]] int n_pad = 0;
   if constexpr (kMulti) {
@@ -227,12 +226,12 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
     sample = is_sample ? a.perm[slot] : 0;
     const double z_dla = m.min_z_dla + (m.max_z_dla - m.min_z_dla) * a.offset_samples[sample];  // :162-164
     const double nhi = a.nhi_samples[sample];
-    my_mult = mult_s + (size_t)(group * kSamplesPerWave + s) * L;
     if (LINES > 0) {
 #pragma unroll
       for (int j = 0; j < LINES; ++j) mult_r[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;  // voigt.c:278-279
-    } else if (role == 0 && jj == 0) {
-      for (int j = 0; j < L; ++j) my_mult[j] = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
+    } else {
+      opz = 1 + z_dla;
+      inv_opz = 1.0 / opz;
     }
     if (tid < kExpTab) exp_tab[tid] = exp2((double)tid * (1.0 / kExpTab));
     lam = a.lam_pad + m.lam_off;
@@ -280,17 +279,12 @@ __global__ __launch_bounds__(512) void k_sweep_split_slim(Args a) {
     if (LINES == 3) {
       total = wing_sum3(lamP, ms_r[0], ms_r[LINES > 1 ? 1 : 0], ms_r[LINES > 2 ? 2 : 0], cs, &near);
     } else {
-      total = 0.0;
-      near = false;
-      for (int j = 0; j < L; ++j) {
-        const double x = fma(lamP, my_mult[j] * inv_s, -cs);
-        const double x2 = x * x;
-        near |= x2 < 900.0;
-        total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
-      }
+      total = wing_sum_runtime(lamP * inv_opz, cs, L, &near);
     }
-    if (__builtin_expect(__any(near), 0))
-      total = total_near<LINES>(lamP, mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], my_mult, L);
+    if (__builtin_expect(__any(near), 0)) {
+      if constexpr (LINES > 0) total = total_near<LINES>(lamP, mult_r[0], mult_r[LINES > 1 ? 1 : 0], mult_r[LINES > 2 ? 2 : 0], nullptr, L);
+      else total = total_near_at(lamP, opz, L);
+    }
     return exp_table_scaled(nscale64 * total, exp_tab);
   };
   auto lam_of = [&](int tr) -> double { return lam[min(4 * tr + jj, n_pad - 1)]; };
