@@ -1479,8 +1479,12 @@ __global__ __launch_bounds__(256, 2) void k_train_core_wide(TrainCoreArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_train_finish: ordered sums.  Blocks 0 .. G-1: pixel p -> dM[p, :] and dlog_omega[p];
-// block G: f and the three scalar gradients.
+// k_train_finish: ordered sums.  Block 0: f and the three scalar gradients (the longest block -- four
+// tree reductions -- so it is dispatched FIRST and runs beside the others instead of being the
+// kernel's tail); blocks 1 .. G: pixel p = block - 1 -> dM[p, :] and dlog_omega[p].  The kernel is
+// latency-bound (95 % of its wave cycles are waits): the splits of a column are requested four at a
+// time and added in split order (the same sum, bit for bit, as one at a time; eight at a time: no
+// further gain).  k = 40: 40 -> 30 us; k = 20: 21 -> 22 (profiles/r05_ab_training_finish.txt).
 // ------------------------------------------------------------------------------------------
 struct TrainFinishArgs {
   TrainDims d;
@@ -1502,14 +1506,22 @@ __global__ __launch_bounds__(256) void k_train_finish(TrainFinishArgs a) {
   const TrainDims &D = a.d;
   const int tid = threadIdx.x, k = D.k;
   const int64_t G = D.G;
-  if ((int64_t)blockIdx.x < G) {
-    const int64_t p = blockIdx.x, pt = p >> 4;
+  if (blockIdx.x > 0) {
+    const int64_t p = (int64_t)blockIdx.x - 1, pt = p >> 4;
     const int ps = (int)(p & 15);
     // (only the 16 (W + U) columns that exist: the padding tiles of the last group are never written)
     for (int e = tid; e < 16 * (K::W + K::U); e += 256) {  // A_p (vech) and C_p: sum of the quasar splits, in order
       const double *pd = a.partD + ((pt * D.H2) * 16 + ps) * (int64_t)K::Cols + e;
       double v = 0.0;
-      for (int h = 0; h < D.H2; ++h) v += pd[(int64_t)h * 16 * K::Cols];
+      int h = 0;
+      for (; h + 4 <= D.H2; h += 4) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = pd[(int64_t)(h + u) * 16 * K::Cols];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v += t[u];
+      }
+      for (; h < D.H2; ++h) v += pd[(int64_t)h * 16 * K::Cols];
       s_a[e] = v;
     }
     __syncthreads();
@@ -1523,7 +1535,16 @@ __global__ __launch_bounds__(256) void k_train_finish(TrainFinishArgs a) {
     }
     if (tid == 64) {
       double v = 0.0;
-      for (int gs = 0; gs < D.GS; ++gs) v += a.partcol[(pt * D.GS + gs) * 16 + ps];
+      const double *pc = a.partcol + (pt * D.GS) * 16 + ps;
+      int gs = 0;
+      for (; gs + 8 <= D.GS; gs += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = pc[(gs + u) * 16];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+      }
+      for (; gs < D.GS; ++gs) v += pc[gs * 16];
       a.g[G * k + p] = -v;  // :62
     }
     return;
