@@ -1337,7 +1337,10 @@ __global__ __launch_bounds__(256, 2) void k_train_core(TrainCoreArgs a) {
 // algorithmic traffic, 27 % of the wave cycles waiting: 0.366 ms.  Two pixel groups per block halve
 // that re-read.)  The waves of a block run the same number of chunks -- a split that has one quasar
 // group fewer idles through the last ones.
-constexpr int kTrWideCH = 12;
+#ifndef TR_WIDE_CH
+#define TR_WIDE_CH 12
+#endif
+constexpr int kTrWideCH = TR_WIDE_CH;  // column steps per chunk (TR_WIDE_CH: for A/B)
 #ifndef TR_WIDE_PB
 #define TR_WIDE_PB 2
 #endif
