@@ -569,35 +569,47 @@ def _spectra_struct(csr: dict, lp_no, lp_dla, lp_lls, keep: list) -> "_lib.Spect
         ptr(lp_dla, np.float64, C.c_double), None if lp_lls is None else ptr(lp_lls, np.float64, C.c_double))
 
 
+_addressof, _char_from_buffer = C.addressof, C.c_char.from_buffer
+
+
+def _data_address(a: np.ndarray) -> int:
+    """Address of an array's first byte.  Through the buffer protocol where that works (a writable,
+    non-empty array: 0.3 us), else through ``__array_interface__`` (1 us: a dict is built per call) --
+    a list of 2048 quasars is 8192 arrays."""
+    try:
+        return _addressof(_char_from_buffer(a))
+    except (TypeError, ValueError, BufferError):
+        return a.__array_interface__["data"][0]
+
+
 def _cells_struct(spectra, lp_no, lp_dla, lp_lls, keep: list) -> "_lib.SpectraCells":
     """gpdla_spectra_cells over a list of per-quasar dicts: pointers to the arrays as they are (an
-    array that is not contiguous float64 -- uint8 / bool for the mask -- is converted, that one only)."""
+    array that is not contiguous float64 -- uint8 / bool for the mask -- is converted, that one only).
+    Column by column, in comprehensions: the per-quasar Python work is what a 2048-quasar call pays
+    before the library starts (5 us per quasar as one loop with ``__array_interface__``, 1.5 us so)."""
     n = len(spectra)
+    f64, u8, b1, nd = np.dtype(np.float64), np.dtype(np.uint8), np.dtype(np.bool_), np.ndarray
     ptrs = np.empty((4, n), dtype=np.uintp)
-    npix = np.empty(n, dtype=np.int64)
-    z = np.empty(n, dtype=np.float64)
-    f64, u8, b1 = np.dtype(np.float64), np.dtype(np.uint8), np.dtype(np.bool_)
-    for i, s in enumerate(spectra):
-        w = s["wavelengths"]
-        if not (isinstance(w, np.ndarray) and w.dtype == f64 and w.flags.c_contiguous):
-            w = np.ascontiguousarray(w, dtype=np.float64)
-        npix[i] = w.size
-        z[i] = s["z_qso"]
-        row = [w]
-        for key in ("flux", "noise_variance"):
-            a = s[key]
-            if not (isinstance(a, np.ndarray) and a.dtype == f64 and a.flags.c_contiguous):
-                a = np.ascontiguousarray(a, dtype=np.float64)
-            row.append(a)
-        m = s["pixel_mask"]
-        if not (isinstance(m, np.ndarray) and (m.dtype == u8 or m.dtype == b1) and m.flags.c_contiguous):
-            m = np.ascontiguousarray(m, dtype=np.uint8)
-        row.append(m)
-        if not (row[1].size == row[2].size == row[3].size == w.size):
-            raise _lib.GpdlaError(-1, f"quasar {i}: wavelengths, flux, noise_variance and pixel_mask differ in length")
-        keep.append(row)
-        for j in range(4):
-            ptrs[j, i] = row[j].__array_interface__["data"][0]
+    sizes = []
+    for j, key in enumerate(("wavelengths", "flux", "noise_variance", "pixel_mask")):
+        col = [s[key] for s in spectra]
+        if j < 3:
+            fix = [i for i, a in enumerate(col) if not (type(a) is nd and a.dtype == f64 and a.flags.c_contiguous)]
+            for i in fix:
+                col[i] = np.ascontiguousarray(col[i], dtype=np.float64)
+        else:
+            fix = [i for i, a in enumerate(col)
+                   if not (type(a) is nd and (a.dtype == u8 or a.dtype == b1) and a.flags.c_contiguous)]
+            for i in fix:
+                col[i] = np.ascontiguousarray(col[i], dtype=np.uint8)
+        keep.append(col)
+        ptrs[j] = [_data_address(a) for a in col]
+        sizes.append(np.array([a.size for a in col], dtype=np.int64))
+    npix = sizes[0]
+    same = (sizes[1] == npix) & (sizes[2] == npix) & (sizes[3] == npix)
+    if not same.all():
+        raise _lib.GpdlaError(-1, f"quasar {int(np.flatnonzero(~same)[0])}: wavelengths, flux, noise_variance and pixel_mask differ in length")
+    z = np.array([s["z_qso"] for s in spectra], dtype=np.float64)
     keep += [ptrs, npix, z]
 
     def dptr(a):

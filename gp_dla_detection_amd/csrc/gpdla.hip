@@ -608,7 +608,14 @@ int batch_fill(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, int md
     b->arena = nullptr;
     b->cap.arena = 0;
     void *p = nullptr;
+#ifdef ONESHOT_EXP_TIMING
+    const auto t_malloc = std::chrono::steady_clock::now();
+#endif
     if (hipMalloc(&p, need) != hipSuccess) return fail(GPDLA_ERR_HIP, "hipMalloc of %zu bytes for a batch failed", need);
+#ifdef ONESHOT_EXP_TIMING
+    std::fprintf(stderr, "[batch] arena of %.1f MB: hipMalloc %.2f ms\n", (double)need / 1e6,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_malloc).count());
+#endif
     b->arena = p;
     b->cap.arena = need;
   }
@@ -1718,6 +1725,9 @@ int plan_blocks(int64_t nq, int64_t longest, const gpdla_config &cfg, int k, int
                                 ? cfg.max_quasars_per_batch
                                 : gpdla_default_batch_quasars(nq, longest, k, S, slots, 0, multi_models);
   for (int64_t lo = 0; lo < nq; lo += per_batch) plan->blocks.emplace_back(lo, std::min(lo + per_batch, nq));
+  // (Measured and not kept, profiles/r05_one_shot_timing.txt: a short last block -- an eighth of a block, so
+  // that the one download nothing overlaps is small.  The call ends ~4 ms behind its last sweep either
+  // way: that tail is the latency of the stage hand-offs and of the copies' synchronisation, not bytes.)
   plan->slots = std::min<size_t>((size_t)slots, plan->blocks.size());
   return GPDLA_OK;
 }
@@ -1843,16 +1853,50 @@ int one_shot_single(const gpdla_model *model, const gpdla_samples *samples, cons
   if (rc) return rc;
   BlockPlan plan;
   if ((rc = plan_blocks(src.num_quasars(), longest, cfg, model->k, samples->num_dla_samples, 0, &plan))) return rc;
+#ifdef ONESHOT_EXP_TIMING  // (diagnostic build: where a one-shot call spends what the sweeps do not; stderr)
+  using clk = std::chrono::steady_clock;
+  const auto t_in = clk::now();
+  auto ms_since = [&](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+  struct Report {
+    clk::time_point t_in;
+    double open = 0, staged0 = 0, up0 = 0, proc0 = 0, proc_last = 0, down_last = 0, pipeline = 0;
+    ~Report() {
+      std::fprintf(stderr, "[one-shot] context open %.2f ms | block 0 staged at %.2f, uploaded at %.2f, launched at %.2f | last launch at %.2f, "
+                   "last download done at %.2f, pipeline returned at %.2f, context closed at %.2f\n", open, staged0, up0, proc0, proc_last,
+                   down_last, pipeline, std::chrono::duration<double, std::milli>(clk::now() - t_in).count());
+    }
+  } report;  // (declared in front of `os`: destroyed behind it)
+  report.t_in = t_in;
+#endif
   OneShot os;
   if ((rc = os.open(model, samples, cfg, device_id))) return rc;
+#ifdef ONESHOT_EXP_TIMING
+  report.open = ms_since(t_in);
+#endif
   os.batches.assign(plan.slots, nullptr);
   const int64_t S = samples->num_dla_samples;
   auto up = [&](size_t i, size_t slot) {
     gpdla_spectra sp;
     if (int r = src.block(plan.blocks[i].first, plan.blocks[i].second, slot, &sp)) return r;
-    return os.batches[slot] ? gpdla_batch_reload(os.c, os.batches[slot], &sp) : gpdla_batch_upload(os.c, &sp, &os.batches[slot]);
+#ifdef ONESHOT_EXP_TIMING
+    if (i == 0) report.staged0 = ms_since(t_in);
+#endif
+    const int r = os.batches[slot] ? gpdla_batch_reload(os.c, os.batches[slot], &sp) : gpdla_batch_upload(os.c, &sp, &os.batches[slot]);
+#ifdef ONESHOT_EXP_TIMING
+    if (i == 0) report.up0 = ms_since(t_in);
+#endif
+    return r;
   };
-  auto proc = [&](size_t, size_t slot) { return gpdla_batch_process(os.c, os.batches[slot]); };
+  auto proc = [&](size_t i, size_t slot) {
+    const int r = gpdla_batch_process(os.c, os.batches[slot]);
+#ifdef ONESHOT_EXP_TIMING
+    if (i == 0) report.proc0 = ms_since(t_in);
+    if (i + 1 == plan.blocks.size()) report.proc_last = ms_since(t_in);
+#else
+    (void)i;
+#endif
+    return r;
+  };
   auto down = [&](size_t i, size_t slot) {
     const int64_t lo = plan.blocks[i].first;
     gpdla_results r;
@@ -1870,10 +1914,18 @@ int one_shot_single(const gpdla_model *model, const gpdla_samples *samples, cons
     r.MAP_inds = shifted(results->MAP_inds, lo, 1);
     r.MAP_z_dlas = shifted(results->MAP_z_dlas, lo, 1);
     r.MAP_log_nhis = shifted(results->MAP_log_nhis, lo, 1);
-    return gpdla_batch_download(os.c, os.batches[slot], &r);
+    const int rd = gpdla_batch_download(os.c, os.batches[slot], &r);
+#ifdef ONESHOT_EXP_TIMING
+    if (i + 1 == plan.blocks.size()) report.down_last = ms_since(t_in);
+#endif
+    return rd;
   };
   auto warm = [&] { prefault_pages(results->sample_log_likelihoods_dla, (size_t)src.num_quasars() * S * sizeof(double)); };
-  return run_host_pipeline(plan.blocks.size(), plan.slots, up, proc, down, warm);
+  rc = run_host_pipeline(plan.blocks.size(), plan.slots, up, proc, down, warm);
+#ifdef ONESHOT_EXP_TIMING
+  report.pipeline = ms_since(t_in);
+#endif
+  return rc;
 }
 
 // multi_dlas/process_qsos_multiple_dlas_meanflux.m:141-495 for every quasar of `src`, pipelined
