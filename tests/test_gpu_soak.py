@@ -73,3 +73,61 @@ def test_repeated_one_shot_calls_leave_nothing_behind():
     assert rss1 - rss0 < 64 << 20, f"host RSS grew by {(rss1 - rss0) / 2**20:.1f} MiB over {rounds} rounds"
     assert fds1 - fds0 <= 4, f"file descriptors: {fds0} -> {fds1}"
     assert tasks1 - tasks0 <= 2 and threading.active_count() == thr0, f"threads: {tasks0} -> {tasks1}"
+
+
+def test_concurrent_one_shot_calls_from_several_threads():
+    """no global state, functions thread-safe.  Three host threads call the one-shot
+    entries at the same time on the same device (each call owns its context, streams and slots; the
+    per-device line tables are made once under a lock; the last error is per thread): every result is
+    bit-equal to the same call made alone, and a failing call in one thread leaves the others alone."""
+    model = synthetic.make_model(20)
+    samples = synthetic.make_samples(96)
+    rng = np.random.default_rng(9)
+    sets = [[synthetic.make_spectrum(8000 + 100 * t + i, int(rng.integers(60, 400)), model, mask_fraction=0.02)
+             for i in range(18)] for t in range(3)]
+    p = MultiParameters(max_dlas=2)
+    cat = synthetic.make_prior_catalog()
+
+    def priors(spectra):
+        n = len(spectra)
+        return (np.full(n, -1.0), np.full(n, -1.0))
+
+    def multi_priors(spectra):
+        z = np.array([s["z_qso"] for s in spectra])
+        return gp.dla_existence_prior_multi(cat["z_qsos"], cat["dla_ind"], z, 0.3, 0.7, p)
+
+    def job(t):
+        sp = sets[t]
+        if t == 0:
+            return gp.process_qsos(model, samples, sp, log_priors=priors(sp), max_quasars_per_batch=4)
+        if t == 1:
+            return gp.process_qsos(model, samples, gp.spectra_to_csr(sp), log_priors=priors(sp), max_quasars_per_batch=5)
+        return gp.process_qsos_multiple_dlas_meanflux(model, samples, sp, multi_priors(sp), params=p, max_quasars_per_batch=6)
+
+    alone = [job(t) for t in range(3)]
+    bad = np.ones((18, 1, 96), dtype=np.uint32)
+    bad[9, 0, 0] = 5000
+    for _ in range(4):
+        got, errors = [None] * 4, [None] * 4
+
+        def run(t):
+            try:
+                if t < 3:
+                    got[t] = job(t)
+                else:  # a fourth caller whose call fails in the middle of its pipeline
+                    gp.process_qsos_multiple_dlas_meanflux(model, samples, sets[2], multi_priors(sets[2]), params=p,
+                                                           base_sample_inds=bad, max_quasars_per_batch=3)
+            except Exception as e:  # noqa: BLE001
+                errors[t] = e
+        threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(120)
+            assert not th.is_alive()
+        assert errors[:3] == [None] * 3, errors
+        assert errors[3] is not None and "exceeds num_dla_samples" in str(errors[3])
+        for t in range(3):
+            for key, want in alone[t].items():
+                if isinstance(want, np.ndarray):
+                    np.testing.assert_array_equal(got[t][key], want, err_msg=f"thread {t}: {key}")
