@@ -45,7 +45,7 @@ _u32p = C.POINTER(C.c_uint32)
 
 
 # gpdla_status (include/gpdla.h)
-ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSITIVE_DEFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_POSITIVE_DEFINITE, ERR_UNSUPPORTED, ERR_HOST = -1, -2, -3, -4, -5, -6
 
 
 class GpdlaError(RuntimeError):
@@ -162,6 +162,7 @@ SYMBOLS = [
     ("gpdla_debug_near_poly", C.c_int, [C.c_int, C.c_double, _dp, _dp]),
     ("gpdla_debug_prepared_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _dp, C.c_int64, _i64p]),
     ("gpdla_debug_philox4x32_10", None, [_u32p, _u32p, _u32p]),
+    ("gpdla_debug_throw", C.c_int, [C.c_int]),
 ]
 
 _lib = None

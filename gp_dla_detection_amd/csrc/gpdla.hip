@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <stdexcept>
 #include <condition_variable>
 #include <cmath>
 #include <cstdarg>
@@ -61,6 +62,15 @@ int fail(int code, const char *fmt, ...) {
   t_error = buf;
   return code;
 }
+
+// No C++ exception leaves the library: one that reaches an extern "C" frame ends the host process
+// (MATLAB through a MEX gateway, Python through ctypes).  Every int-returning entry point is a
+// function-try-block closed by this: std::bad_alloc / std::length_error of a host container and
+// anything else unexpected become GPDLA_ERR_HOST with a message.
+#define GPDLA_NO_THROW                                                                                    \
+  catch (const std::bad_alloc &) { return fail(GPDLA_ERR_HOST, "out of host memory"); }                   \
+  catch (const std::exception &e) { return fail(GPDLA_ERR_HOST, "unexpected C++ exception: %s", e.what()); } \
+  catch (...) { return fail(GPDLA_ERR_HOST, "unexpected C++ exception"); }
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -313,7 +323,7 @@ void gpdla_default_config(gpdla_config *cfg) {
 
 /* ------------------------------ context ------------------------------ */
 
-int gpdla_context_create(int device_id, gpdla_context **out) {
+int gpdla_context_create(int device_id, gpdla_context **out) try {
   if (!out) return fail(GPDLA_ERR_INVALID_ARGUMENT, "ctx out pointer is null");
   *out = nullptr;
   int rc = select_device(device_id);
@@ -333,7 +343,7 @@ int gpdla_context_create(int device_id, gpdla_context **out) {
   gpdla_default_config(&c->cfg);
   *out = c;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
 void gpdla_context_destroy(gpdla_context *c) {
   if (!c) return;
@@ -364,7 +374,7 @@ void gpdla_context_destroy(gpdla_context *c) {
   delete c;
 }
 
-int gpdla_context_set_stream(gpdla_context *c, void *hip_stream) {
+int gpdla_context_set_stream(gpdla_context *c, void *hip_stream) try {
   if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
   hipStream_t next = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
   if (next != c->stream && c->d_prof) {
@@ -375,9 +385,9 @@ int gpdla_context_set_stream(gpdla_context *c, void *hip_stream) {
   }
   c->stream = next;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_context_set_config(gpdla_context *c, const gpdla_config *cfg) {
+int gpdla_context_set_config(gpdla_context *c, const gpdla_config *cfg) try {
   if (!c || !cfg) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context/config");
   if (cfg->width != 3)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "width must be 3 (voigt.c:229 hard-codes the 7-tap profile)");
@@ -387,24 +397,24 @@ int gpdla_context_set_config(gpdla_context *c, const gpdla_config *cfg) {
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "contraction_precision must be 0 (fp64) or 1 (fp32 study)");
   c->cfg = *cfg;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_context_set_first_quasar_index(gpdla_context *c, int64_t first_quasar_index) {
+int gpdla_context_set_first_quasar_index(gpdla_context *c, int64_t first_quasar_index) try {
   if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
   c->cfg.first_quasar_index = first_quasar_index;  // (no upload path reads this field)
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_context_synchronize(gpdla_context *c) {
+int gpdla_context_synchronize(gpdla_context *c) try {
   if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
   HIP_TRY(hipSetDevice(c->device_id));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipStreamSynchronize(c->up_stream));
   HIP_TRY(hipStreamSynchronize(c->down_stream));
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_context_set_model(gpdla_context *c, const gpdla_model *m) {
+int gpdla_context_set_model(gpdla_context *c, const gpdla_model *m) try {
   if (!c || !m || !m->rest_wavelengths || !m->mu || !m->M || !m->log_omega)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null model field");
   if (m->num_rest_pixels < 2 || m->k < 1)
@@ -434,9 +444,9 @@ int gpdla_context_set_model(gpdla_context *c, const gpdla_model *m) {
   c->model.beta = std::exp(m->log_beta);
   c->has_model = true;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_context_set_samples(gpdla_context *c, const gpdla_samples *s) {
+int gpdla_context_set_samples(gpdla_context *c, const gpdla_samples *s) try {
   if (!c || !s || !s->offset_samples || !s->nhi_samples || s->num_dla_samples < 1)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/empty samples");
   HIP_TRY(hipSetDevice(c->device_id));
@@ -465,9 +475,9 @@ int gpdla_context_set_samples(gpdla_context *c, const gpdla_samples *s) {
   c->S = (int64_t)S;
   c->has_samples = true;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_context_set_timing(gpdla_context *c, int enabled) {
+int gpdla_context_set_timing(gpdla_context *c, int enabled) try {
   if (!c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null context");
   HIP_TRY(hipSetDevice(c->device_id));
   if (enabled && !c->ev0) {
@@ -477,7 +487,7 @@ int gpdla_context_set_timing(gpdla_context *c, int enabled) {
   c->timing = enabled != 0;
   c->have_timing = false;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
 double gpdla_context_last_sweep_ms(gpdla_context *c) {
   if (!c || !c->have_timing) return -1.0;
@@ -683,7 +693,7 @@ int batch_fill(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp, int md
 
 extern "C" {
 
-int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **out) {
+int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **out) try {
   if (!c || !sp || !out) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
   int md = 0;
@@ -707,9 +717,9 @@ int gpdla_batch_upload(gpdla_context *c, const gpdla_spectra *sp, gpdla_batch **
   }
   *out = b;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_batch_reload(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp) {
+int gpdla_batch_reload(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp) try {
   if (!c || !b || !sp || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
   int md = 0;
   int rc = validate_spectra(c, sp, &md);
@@ -720,7 +730,7 @@ int gpdla_batch_reload(gpdla_context *c, gpdla_batch *b, const gpdla_spectra *sp
   HIP_TRY(hipEventSynchronize(b->ev_done));
   HIP_TRY(hipStreamSynchronize(c->down_stream));
   return batch_fill(c, b, sp, md);  // on failure the batch stays valid to destroy, not to process
-}
+} GPDLA_NO_THROW
 
 }  // extern "C"
 
@@ -936,7 +946,7 @@ int launch_build_records(gpdla_context *c, gpdla_batch *b, int64_t g0, int64_t g
 
 extern "C" {
 
-int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
+int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) try {
   if (!c || !b || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
   if (b->S != c->S || b->k != c->model.k)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "model/samples changed after the batch was uploaded");
@@ -1041,26 +1051,26 @@ int gpdla_batch_process(gpdla_context *c, gpdla_batch *b) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev_done, st));
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_batch_summary_device_ptr(gpdla_batch *b, double **table, int64_t *nq) {
+int gpdla_batch_summary_device_ptr(gpdla_batch *b, double **table, int64_t *nq) try {
   if (!b || !table) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA batch: use gpdla_batch_summary_multi_device_ptr");
   *table = b->d_summary;
   if (nq) *nq = b->nq;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_batch_samples_device_ptr(gpdla_batch *b, double **table, int64_t *nq, int64_t *S) {
+int gpdla_batch_samples_device_ptr(gpdla_batch *b, double **table, int64_t *nq, int64_t *S) try {
   if (!b || !table) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA batch: use gpdla_batch_samples_multi_device_ptr");
   *table = b->d_sample_ll;
   if (nq) *nq = b->nq;
   if (S) *S = b->S;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) {
+int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) try {
   if (!c || !b || !r || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched argument");
   if (b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA batch: use gpdla_batch_download_multi");
   HIP_TRY(hipSetDevice(c->device_id));
@@ -1099,12 +1109,12 @@ int gpdla_batch_download(gpdla_context *c, gpdla_batch *b, gpdla_results *r) {
     if (r->MAP_log_nhis) r->MAP_log_nhis[q] = s[14];
   }
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
 /* ------------------------------ stand-alone surfaces ------------------------------ */
 
 int gpdla_voigt(const double *lambdas, int64_t n_padded, double z, double N, int num_lines,
-                double *profile_out, int device_id) {
+                double *profile_out, int device_id) try {
   if (!lambdas || !profile_out) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null pointer");
   if (n_padded <= 6) return fail(GPDLA_ERR_INVALID_ARGUMENT, "n_padded = %lld must exceed 2*width = 6", (long long)n_padded);
   if (num_lines < 1 || num_lines > kMaxLines)
@@ -1137,10 +1147,10 @@ int gpdla_voigt(const double *lambdas, int64_t n_padded, double z, double N, int
   cleanup();
   if (e != hipSuccess) return fail(GPDLA_ERR_HIP, "gpdla_voigt: %s", hipGetErrorString(e));
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
 int gpdla_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M, const double *d,
-                              int64_t n, int k, double *log_p, int device_id) {
+                              int64_t n, int k, double *log_p, int device_id) try {
   if (!y || !mu || !M || !d || !log_p) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null pointer");
   if (n < 1 || k < 1) return fail(GPDLA_ERR_INVALID_ARGUMENT, "n and k must be positive");
   if (k > 256) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d too large", k);
@@ -1175,7 +1185,7 @@ int gpdla_log_mvnpdf_low_rank(const double *y, const double *mu, const double *M
     return fail(GPDLA_ERR_NOT_POSITIVE_DEFINITE, "B = I + M' D^-1 M is not positive definite");
   }
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
 }  // extern "C"
 
@@ -1347,7 +1357,7 @@ int multi_alloc(gpdla_batch *b) {
 
 extern "C" {
 
-int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *base_in) {
+int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *base_in) try {
   if (!c || !b || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched context or batch");
   if (!b->md) return fail(GPDLA_ERR_INVALID_ARGUMENT, "not a multi-DLA batch (upload it with log_priors_lls)");
   if (b->S != c->S || b->k != c->model.k)
@@ -1523,9 +1533,9 @@ int gpdla_batch_process_multi(gpdla_context *c, gpdla_batch *b, const uint32_t *
   HIP_TRY(hipEventRecord(b->ev_done, st));
   mb.processed = true;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_batch_download_multi(gpdla_context *c, gpdla_batch *b, gpdla_results_multi *r) {
+int gpdla_batch_download_multi(gpdla_context *c, gpdla_batch *b, gpdla_results_multi *r) try {
   if (!c || !b || !r || b->ctx != c) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null/mismatched argument");
   if (!b->md || !b->mb || !b->mb->processed)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "no multi-DLA results: call gpdla_batch_process_multi first");
@@ -1569,9 +1579,9 @@ int gpdla_batch_download_multi(gpdla_context *c, gpdla_batch *b, gpdla_results_m
     if (r->status) r->status[q] = meta[q].status;
   }
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_batch_summary_multi_device_ptr(gpdla_batch *b, double **table, int64_t *nq, int32_t *cols) {
+int gpdla_batch_summary_multi_device_ptr(gpdla_batch *b, double **table, int64_t *nq, int32_t *cols) try {
   if (!b || !table) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (!b->md || !b->mb || !b->mb->summary)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "no multi-DLA results: call gpdla_batch_process_multi first");
@@ -1579,10 +1589,10 @@ int gpdla_batch_summary_multi_device_ptr(gpdla_batch *b, double **table, int64_t
   if (nq) *nq = b->nq;
   if (cols) *cols = GPDLA_SUMMARY_COLS_MULTI(b->md);
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
 int gpdla_batch_samples_multi_device_ptr(gpdla_batch *b, double **sll_dla, double **sll_lls,
-                                         uint32_t **base) {
+                                         uint32_t **base) try {
   if (!b) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (!b->md || !b->mb || !b->mb->sll_dla)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "no multi-DLA results: call gpdla_batch_process_multi first");
@@ -1590,7 +1600,7 @@ int gpdla_batch_samples_multi_device_ptr(gpdla_batch *b, double **sll_dla, doubl
   if (sll_lls) *sll_lls = b->mb->sll_lls;
   if (base) *base = b->mb->base;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
 }  // extern "C"
 
@@ -1655,9 +1665,15 @@ int run_host_pipeline(size_t nblocks, size_t slots, Up up, Proc proc, Down down,
   auto guarded = [&](auto &&body) {
     try {
       body();
+    } catch (const std::bad_alloc &) {
+      fail(GPDLA_ERR_HOST, "host pipeline: out of host memory");
+      ps.raise(GPDLA_ERR_HOST);
     } catch (const std::exception &e) {
-      fail(GPDLA_ERR_HIP, "host pipeline: %s", e.what());
-      ps.raise(GPDLA_ERR_HIP);
+      fail(GPDLA_ERR_HOST, "host pipeline: %s", e.what());
+      ps.raise(GPDLA_ERR_HOST);
+    } catch (...) {  // (a stage thread that lets an exception escape ends the process)
+      fail(GPDLA_ERR_HOST, "host pipeline: unexpected C++ exception");
+      ps.raise(GPDLA_ERR_HOST);
     }
   };
   auto upload_stage = [&] {
@@ -1686,8 +1702,8 @@ int run_host_pipeline(size_t nblocks, size_t slots, Up up, Proc proc, Down down,
     uploader = std::thread(upload_stage);
     downloader = std::thread(download_stage);
   } catch (const std::exception &e) {
-    fail(GPDLA_ERR_HIP, "host pipeline: cannot start a thread: %s", e.what());
-    ps.raise(GPDLA_ERR_HIP);
+    fail(GPDLA_ERR_HOST, "host pipeline: cannot start a thread: %s", e.what());
+    ps.raise(GPDLA_ERR_HOST);
   }
   guarded([&] {
     for (size_t i = 0; i < nblocks; ++i) {
@@ -2006,17 +2022,17 @@ int64_t gpdla_default_batch_quasars(int64_t num_quasars, int64_t longest_spectru
 
 int gpdla_process_batch(const gpdla_model *model, const gpdla_samples *samples,
                         const gpdla_spectra *spectra, const gpdla_config *config,
-                        gpdla_results *results, int device_id) {
+                        gpdla_results *results, int device_id) try {
   if (!model || !samples || !spectra || !results)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (spectra->log_priors_lls)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "log_priors_lls given: use gpdla_process_batch_multi");
   return one_shot_single(model, samples, CsrSource{spectra, 0}, config, results, device_id);
-}
+} GPDLA_NO_THROW
 
 int gpdla_process_cells(const gpdla_model *model, const gpdla_samples *samples,
                         const gpdla_spectra_cells *spectra, const gpdla_config *config,
-                        gpdla_results *results, int device_id) {
+                        gpdla_results *results, int device_id) try {
   if (!model || !samples || !spectra || !results)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (spectra->log_priors_lls)
@@ -2024,12 +2040,12 @@ int gpdla_process_cells(const gpdla_model *model, const gpdla_samples *samples,
   CellSource src{spectra, 0, {}};
   src.staging.resize(config && config->pipeline_slots > 0 ? (size_t)config->pipeline_slots : 3);
   return one_shot_single(model, samples, src, config, results, device_id);
-}
+} GPDLA_NO_THROW
 
 int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *samples,
                               const gpdla_spectra *spectra, const uint32_t *base_sample_inds,
                               const gpdla_config *config, gpdla_results_multi *results,
-                              int device_id) {
+                              int device_id) try {
   if (!model || !samples || !spectra || !results)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (!spectra->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
@@ -2037,12 +2053,12 @@ int gpdla_process_batch_multi(const gpdla_model *model, const gpdla_samples *sam
   gpdla_default_config(&cfg);
   if (config) cfg = *config;
   return one_shot_multi(model, samples, CsrSource{spectra, cfg.max_dlas}, base_sample_inds, config, results, device_id);
-}
+} GPDLA_NO_THROW
 
 int gpdla_process_cells_multi(const gpdla_model *model, const gpdla_samples *samples,
                               const gpdla_spectra_cells *spectra, const uint32_t *base_sample_inds,
                               const gpdla_config *config, gpdla_results_multi *results,
-                              int device_id) {
+                              int device_id) try {
   if (!model || !samples || !spectra || !results)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (!spectra->log_priors_lls) return fail(GPDLA_ERR_INVALID_ARGUMENT, "multi-DLA needs log_priors_lls");
@@ -2052,11 +2068,18 @@ int gpdla_process_cells_multi(const gpdla_model *model, const gpdla_samples *sam
   CellSource src{spectra, cfg.max_dlas, {}};
   src.staging.resize(cfg.pipeline_slots > 0 ? (size_t)cfg.pipeline_slots : 3);
   return one_shot_multi(model, samples, src, base_sample_inds, config, results, device_id);
-}
+} GPDLA_NO_THROW
 
 void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
+
+int gpdla_debug_throw(int kind) try {
+  if (kind == 1) throw std::bad_alloc();
+  if (kind == 2) throw std::runtime_error("thrown on request");
+  if (kind == 3) throw 42;
+  return GPDLA_OK;
+} GPDLA_NO_THROW
 
 /* ------------------------------ training objective (N3) ------------------------------ */
 
@@ -2136,7 +2159,7 @@ void gpdla_training_destroy(gpdla_training *t) {
 }
 
 int gpdla_training_create(int device_id, int64_t nq, int64_t G, const double *flux, const double *lya,
-                          const double *noise, gpdla_training **out) {
+                          const double *noise, gpdla_training **out) try {
   if (!out || !flux || !lya || !noise) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
   if (nq < 1 || G < 1) return fail(GPDLA_ERR_INVALID_ARGUMENT, "empty training set");
@@ -2173,7 +2196,7 @@ int gpdla_training_create(int device_id, int64_t nq, int64_t G, const double *fl
   }
   *out = t;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
 }  // extern "C"
 
@@ -2436,7 +2459,7 @@ int training_objective_mfma(gpdla_training *t, int k, double *f, double *g) {
 extern "C" {
 
 int gpdla_training_set_lyseries(gpdla_training *t, int num_forest_lines, const double *all_transition_wavelengths,
-                                const double *all_oscillator_strengths) {
+                                const double *all_oscillator_strengths) try {
   if (!t) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null training set");
   if (num_forest_lines < 0 || num_forest_lines > kTrMaxLines)
     return fail(GPDLA_ERR_INVALID_ARGUMENT, "num_forest_lines = %d outside [0, %d]", num_forest_lines, kTrMaxLines);
@@ -2488,9 +2511,9 @@ int gpdla_training_set_lyseries(gpdla_training *t, int num_forest_lines, const d
   if (bad) return fail(GPDLA_ERR_UNSUPPORTED, "the active Lyman lines of some pixel are not a prefix of the series");
   t->lines = L;
   return GPDLA_OK;
-}
+} GPDLA_NO_THROW
 
-int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *f, double *g) {
+int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *f, double *g) try {
   if (!t || !x || !f || !g) return fail(GPDLA_ERR_INVALID_ARGUMENT, "null argument");
   if (k < 1 || k > GPDLA_MAX_K) return fail(GPDLA_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, GPDLA_MAX_K);
   HIP_TRY(hipSetDevice(t->device_id));
@@ -2570,7 +2593,7 @@ int gpdla_training_objective(gpdla_training *t, const double *x, int k, double *
 #else
   return GPDLA_OK;  // (not reached: `legacy` is false in the product library)
 #endif
-}
+} GPDLA_NO_THROW
 
 }  // extern "C"
 

@@ -34,7 +34,9 @@ typedef enum {
   GPDLA_ERR_NO_DEVICE = -2,        /* no HIP device / device_id out of range */
   GPDLA_ERR_HIP = -3,              /* a HIP runtime call failed; see gpdla_last_error() */
   GPDLA_ERR_NOT_POSITIVE_DEFINITE = -4, /* chol(B) would throw, log_mvnpdf_low_rank.m:24 */
-  GPDLA_ERR_UNSUPPORTED = -5       /* e.g. k > GPDLA_MAX_K */
+  GPDLA_ERR_UNSUPPORTED = -5,      /* e.g. k > GPDLA_MAX_K */
+  GPDLA_ERR_HOST = -6              /* host side: out of memory, a stage thread could not be started, or an
+                                      unexpected C++ exception -- none ever crosses this boundary */
 } gpdla_status;
 
 #define GPDLA_MAX_K 40
@@ -399,6 +401,12 @@ int gpdla_debug_prepared_rows(gpdla_context *ctx, gpdla_batch *batch, int multi,
  * SC'11), evaluated on the HOST by the same function the kernel compiles: out = philox(ctr, key).
  * For known-answer tests against the Random123 vectors.  Needs no GPU. */
 void gpdla_debug_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* Test hook for the boundary itself: throws, inside an entry point's body, std::bad_alloc (kind 1),
+ * std::runtime_error (2) or a non-standard exception (3); kind 0 returns GPDLA_OK.  Every
+ * int-returning entry point ends in the same handlers: the caller gets GPDLA_ERR_HOST and a message,
+ * never a C++ exception (which would end MATLAB / Python).  Needs no GPU. */
+int gpdla_debug_throw(int kind);
 
 #ifdef __cplusplus
 }

@@ -201,6 +201,24 @@ def test_one_shot_entry_validates_before_it_touches_the_gpu(lib):
     assert lib.gpdla_process_batch(C.byref(m), C.byref(s_), None, C.byref(cfg), C.byref(r), 0) == -1
 
 
+def test_no_cpp_exception_crosses_the_boundary(lib):
+    """An exception that reaches an extern "C" frame ends the host process (MATLAB through the MEX gateways
+    of integration/, Python through ctypes).  Every int-returning entry point of csrc/gpdla.hip is a
+    function-try-block closed by the same handlers; the hook throws inside one."""
+    assert lib.gpdla_debug_throw(0) == 0
+    for kind, text in ((1, b"out of host memory"), (2, b"thrown on request"), (3, b"unexpected C++ exception")):
+        assert lib.gpdla_debug_throw(kind) == _lib.ERR_HOST == -6
+        assert text in lib.gpdla_last_error()
+    # and every such entry point in the source is closed that way
+    src = open(os.path.join(ROOT, "gp_dla_detection_amd", "csrc", "gpdla.hip")).read()
+    blocks = re.findall(r'extern "C" \{(.*?)\}  // extern "C"', src, flags=re.S)
+    defs = [m for b in blocks for m in re.findall(r"^int (gpdla_\w+)\([^;{]*?\)\s*(try )?\{", b, flags=re.M | re.S)]
+    assert len(defs) >= 28
+    unguarded = [name for name, guarded in defs if not guarded and name != "gpdla_abi_version"]
+    assert unguarded == [], unguarded
+    assert src.count("} GPDLA_NO_THROW") == sum(1 for _, g in defs if g)
+
+
 def test_default_batch_rule(lib):
     """gpdla_default_batch_quasars: ~8 batches per run, >= 128 and <= 4096 quasars, `slots` batches within
     the HBM budget; the multi-DLA driver's batches are smaller (2 x models sample tables + records)."""
