@@ -437,7 +437,7 @@ def record_bytes_per_quasar(num_pixels: int, k: int, slim: bool = True) -> int:
     the record pool: 896 B per step for k <= 20 (k_sweep_slim / k_sweep_multi_slim: the M rows, pixel
     rows and wavelengths), 1536 B for 20 < k <= 40 (k_sweep_split_slim: the M rows);
     ``slim=False``: the pre-expanded records of k_sweep / k_sweep_split -- 7680 B and 29 696 B --
-    used for other line counts at k <= 20, the fp32 study and libgpdla_legacy.so's ``GPDLA_EXPANDED_RECORDS=1``.  The
+    used by the fp32 study and libgpdla_legacy.so's ``GPDLA_EXPANDED_RECORDS=1`` only (every fp64 line count has slim records).  The
     pool of the single-DLA sweep is bounded by ``Parameters.record_pool_bytes`` whatever the batch
     size (the library sweeps group by group)."""
     per_step = ((896 if slim else 7680) if k <= 20 else (1536 if slim else 29696))
