@@ -90,8 +90,9 @@ __global__ __launch_bounds__(kProfWaves * 64) void k_profiles(ProfilesArgs a) {
     ms[j] = mult[j] * inv_s;
   }
   const double cs = c_light * inv_s;
+  const double inv_opz = 1.0 / (1 + z_dla);  // (run-time line counts: wing_sum_runtime)
 #ifdef PROF_EXP_RHOTABLE
-  const double inv1pz = 1.0 / (1 + z_dla);
+  const double inv1pz = inv_opz;
 #endif
   // (pre-scaled exp, sweep_kernels.hpp)
   const double nscale_a = -a.nhi_samples[i] * g_lines.inv_sqrt2pi_sigma * kInvSqrtPi * kExpScale;
@@ -133,23 +134,20 @@ __global__ __launch_bounds__(kProfWaves * 64) void k_profiles(ProfilesArgs a) {
 #else
       total = wing_sum3(lamP, ms[0], ms[1], ms[2], cs, &near);
 #endif
-    } else {
-      for (int j = 0; j < L; ++j) {
-        const double mj = g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
-        const double x = (lamP * mj - c_light) * inv_s;  // voigt.c:287
-        const double x2 = x * x;
-        near |= x2 < 900.0;
-        total = fma(g_lines.cwing[j], wing_core(x2, g_lines.y2[j]), total);
-      }
+    } else {  // a run-time line count: the wing tier of k_sweep_slim<0> (four lines at a time from rho = lambda / (1 + z))
+      total = wing_sum_runtime(lamP * inv_opz, cs, L, &near);
     }
     if (__any(near)) {  // accurate tier: per-line piecewise polynomials (near_tables.hpp), as in k_sweep
-      total = 0.0;
-      for (int j = 0; j < L; ++j) {
-        const double mj = j < 3 ? mult[j] : g_lines.c / (g_lines.wavelength_cm[j] * (1 + z_dla)) / 1e8;
-        const double ax = fabs((lamP * mj - c_light) * inv_s);
-        total += ax < 30.0 ? 1.7724538509055159 * g_lines.leading[j] *
-                                 near_poly(g_lines.near_poly + j * kNearLineDoubles, ax)
-                           : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
+      if (L == 3) {
+        total = 0.0;
+        for (int j = 0; j < 3; ++j) {
+          const double ax = fabs((lamP * mult[j] - c_light) * inv_s);
+          total += ax < 30.0 ? 1.7724538509055159 * g_lines.leading[j] *
+                                   near_poly(g_lines.near_poly + j * kNearLineDoubles, ax)
+                             : g_lines.cwing[j] * wing_core(ax * ax, g_lines.y2[j]);
+        }
+      } else {
+        total = total_near_at(lamP, 1 + z_dla, L);
       }
     }
     return total;

@@ -24,10 +24,12 @@ def priors(spectra, p):
 
 
 def oracle_multi(oracle, model, samples, sp, bsi, p):
+    from oracle.oracle import OracleParams
     return oracle.process_spectrum_multi(
         model, samples["offset_samples"], samples["nhi_samples"], samples["log_nhi_samples"],
         samples["lls_nhi_samples"], bsi, sp["wavelengths"], sp["flux"], sp["noise_variance"],
-        sp["pixel_mask"], sp["z_qso"], max_dlas=p.max_dlas, num_forest_lines=p.num_forest_lines,
+        sp["pixel_mask"], sp["z_qso"], params=OracleParams(num_lines=p.num_lines), max_dlas=p.max_dlas,
+        num_forest_lines=p.num_forest_lines,
         min_z_separation=p.min_z_separation, prev_tau_0=p.prev_tau_0, prev_beta=p.prev_beta)
 
 
@@ -144,6 +146,20 @@ def test_rank_40_multi_dla(oracle):
     spectra = [synthetic.make_spectrum(80 + i, n, model, mask_fraction=0.04) for i, n in enumerate([260, 301])]
     lp = priors(spectra, p)
     out = gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=p)
+    for i, sp in enumerate(spectra):
+        compare(out, i, oracle_multi(oracle, model, samples, sp, out["base_sample_inds"][i], p), p)
+
+
+@pytest.mark.parametrize("k,num_lines", [(20, 31), (20, 5), (33, 31), (12, 1)])
+def test_multi_dla_at_other_line_counts(oracle, k, num_lines):
+    """The Voigt profile table (k_profiles) at a line count other than set_parameters_multi's three
+    (voigt.c:16, 266 default to all 31): the run-time wing tier the single-DLA sweeps use
+    (wing_sum_runtime) and the reference's own multiplier in the near tier, against the oracle."""
+    p = MultiParameters(max_dlas=3, num_lines=num_lines)
+    model = synthetic.make_model(k)
+    samples = synthetic.make_samples(80)
+    spectra = [synthetic.make_spectrum(300 + 10 * num_lines + i, n, model, mask_fraction=0.03) for i, n in enumerate([222, 407])]
+    out = gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, priors(spectra, p), params=p)
     for i, sp in enumerate(spectra):
         compare(out, i, oracle_multi(oracle, model, samples, sp, out["base_sample_inds"][i], p), p)
 

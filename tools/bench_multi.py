@@ -23,10 +23,11 @@ ap.add_argument("--pixels", type=int, default=1500)
 ap.add_argument("--samples", type=int, default=10000)
 ap.add_argument("--max-dlas", type=int, default=4)
 ap.add_argument("--k", type=int, default=20)
+ap.add_argument("--num-lines", type=int, default=3, help="Lyman lines of the Voigt profiles (a diagnostic: production is 3)")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--pcie-batches", type=int, default=6, help="batches of --spectra in the host-to-host (PCIe-inclusive) call")
 args = ap.parse_args()
-p = MultiParameters(max_dlas=args.max_dlas)
+p = MultiParameters(max_dlas=args.max_dlas, num_lines=args.num_lines)
 model = synthetic.make_model(args.k)
 samples = synthetic.make_samples(args.samples)
 base = synthetic.make_spectra(min(8, args.spectra), args.pixels, model, first_index=500)
