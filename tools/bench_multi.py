@@ -59,6 +59,14 @@ ctx.close()
 # allocations), then --pcie-batches times the batch in one call (upload i+1 / sweep i / download i-1)
 gp.process_qsos_multiple_dlas_meanflux(model, samples, spectra, lp, params=p)
 nb = args.pcie_batches
+if nb < 1:  # (--pcie-batches 0: the resident part only, e.g. under the profiler)
+    flops = evals * (args.pixels * args.k * (args.k + 3) + args.k ** 3 / 3.0)
+    print(json.dumps({"metric": "multi-DLA sample log-likelihoods/sec (resident in HBM)", "value": evals / wall,
+                      "gpu_ms_per_call": float(np.mean(ms)), "wall_ms_per_call": wall * 1e3,
+                      "algorithmic_tflops": flops / (np.mean(ms) * 1e-3) / 1e12, "spectra": args.spectra,
+                      "pixels": args.pixels, "samples": args.samples, "max_dlas": args.max_dlas, "k": args.k,
+                      "num_lines": args.num_lines, "evaluations": evals}))
+    raise SystemExit(0)
 big = [spectra[i % len(spectra)] for i in range(nb * args.spectra)]
 lpb = tuple(np.concatenate([np.asarray(v)] * nb, axis=0) for v in lp)
 # every call makes its own context and with it a 15 GB profile table: the first such allocations of a
