@@ -521,7 +521,7 @@ def main():
                          f"profiles/pmc_latest.json{', tag ' + traffic_tag if traffic_tag else ''}; null unless "
                          "measured on this libgpdla.so and workload)",
                          # (GPDLA_EXPANDED_RECORDS only means something to libgpdla_legacy.so, loaded through GPDLA_LIB_PATH by the A/B tools)
-                         "kernel": ("k_sweep_slim" if args.k <= 20 and args.contraction == "f64"
+                         "kernel": (("k_sweep_slim<3>" if args.num_lines == 3 else "k_sweep_slim<0>") if args.k <= 20 and args.contraction == "f64"
                                     and not os.environ.get("GPDLA_EXPANDED_RECORDS") else
                                     ("k_sweep_split" if os.environ.get("GPDLA_EXPANDED_RECORDS") else "k_sweep_split_slim")
                                     if args.k > 20 and args.contraction == "f64" else "k_sweep"),
