@@ -1210,6 +1210,31 @@ __device__ __forceinline__ double wing_sum3(double lamP, double msa, double msb,
   return fma(g_lines.cwing[2], rc * tc, fma(g_lines.cwing[1], rb * tb, g_lines.cwing[0] * (ra * ta)));
 }
 
+// wing_sum3 with the K-step's OTHER reciprocal riding along: 1/d of the weights (process_qsos.m:192-198
+// folded into log_mvnpdf_low_rank.m:13-15; d is finite and positive, k_prepare sees to that) comes out
+// of the same v_rcp_f64 as the three lines' 1/s_j -- prefix products, one reciprocal of s_a s_b s_c d,
+// peeled: 9 multiplies and one fast_rcp instead of 7 multiplies and two (v_rcp_f64 issues in 17 cycles,
+// a multiply in 5.4: tools/valu_rate_probe.hip).  s_j in [2e-7, 2e9] and d in (0, 1e300): the product
+// stays normal.  Each quotient carries two or three more roundings than fast_rcp's 2.2e-15.
+__device__ __forceinline__ double wing_sum3_rcp4(double lamP, double msa, double msb, double msc, double cs,
+                                                 bool *near, double d, double *inv_d) {
+  const double xa = fma(lamP, msa, -cs), xb = fma(lamP, msb, -cs), xc = fma(lamP, msc, -cs);
+  const double sa = fma(xa, xa, g_lines.y2[0]), sb = fma(xb, xb, g_lines.y2[1]), sc = fma(xc, xc, g_lines.y2[2]);
+  *near = min(min(hi_word(sa), hi_word(sb)), hi_word(sc)) < 0x408C2000u;
+  const double pab = sa * sb, pabc = pab * sc;
+  const double rinv = fast_rcp(pabc * d);
+  *inv_d = rinv * pabc;
+  const double r3 = rinv * d;            // 1 / (sa sb sc)
+  const double rc = r3 * pab, r2 = r3 * sc;  // 1 / sc, 1 / (sa sb)
+  const double ra = r2 * sb, rb = r2 * sa;
+  double ta = ra * kE5 + kE4, tb = rb * kE5 + kE4, tc = rc * kE5 + kE4;
+  ta = fma(ta, ra, kE3); tb = fma(tb, rb, kE3); tc = fma(tc, rc, kE3);
+  ta = fma(ta, ra, g_lines.t2[0]); tb = fma(tb, rb, g_lines.t2[1]); tc = fma(tc, rc, g_lines.t2[2]);
+  ta = fma(ta, ra, kE1); tb = fma(tb, rb, kE1); tc = fma(tc, rc, kE1);
+  ta = fma(ta, ra, 1.0); tb = fma(tb, rb, 1.0); tc = fma(tc, rc, 1.0);
+  return fma(g_lines.cwing[2], rc * tc, fma(g_lines.cwing[1], rb * tb, g_lines.cwing[0] * (ra * ta)));
+}
+
 constexpr int kRing2 = 33;   // doubled raw-profile ring: 32 slots + 1 pad per sample
 constexpr int kExpTab = 64;  // entries of the 2^(j/64) table behind exp_table()
 
@@ -1557,12 +1582,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
         const double2 p23 = *reinterpret_cast<const double2 *>(mine + 2);
         const double py = p01.x, pmu = p01.y, pom = p23.x, pnu = p23.y;
         __builtin_amdgcn_sched_barrier(0);  // keep the reads up here (the scheduler sinks them)
+        // (2) instrument broadening for pixel 4 rn + jj: voigt.c:297-299 (symmetric taps) -- in front of
+        // (1) since round 5: the three-line wing tier takes d along (wing_sum3_rcp4)
+        double absorb = fma(g6, tap0, g0 * tap0);
+        {
+          double ab2 = fma(g5, tap1, g1 * tap1);
+          absorb = fma(g2, tap2, absorb);
+          ab2 = fma(g4, tap2, ab2);
+          absorb = fma(g3, tap3, absorb) + ab2;
+        }
+        if (is_null) absorb = 1.0;
+        const double a2 = absorb * absorb;
+        const double d = fma(pom, a2, pnu);
+        double inv_d;
         // (1) raw profile three K-steps ahead: voigt.c:282-292
         double total;
         bool near;
         if (LINES == 3) {
-          total = wing_sum3(lamP, ms_r[0], ms_r[LINES > 1 ? 1 : 0], ms_r[LINES > 2 ? 2 : 0], cs, &near);
+          total = wing_sum3_rcp4(lamP, ms_r[0], ms_r[LINES > 1 ? 1 : 0], ms_r[LINES > 2 ? 2 : 0], cs, &near, d, &inv_d);
         } else {
+          inv_d = fast_rcp(d);
           total = 0.0;
           near = false;
           for (int j = 0; j < L; ++j) {
@@ -1603,18 +1642,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_sweep(SweepArgs a) {
 #endif
         my_ring[slot_w] = raw;
         my_ring[slot_w + 16] = raw;
-        // (2) instrument broadening for pixel 4 rn + jj: voigt.c:297-299 (symmetric taps)
-        double absorb = fma(g6, tap0, g0 * tap0);
-        double ab2 = fma(g5, tap1, g1 * tap1);
-        absorb = fma(g2, tap2, absorb);
-        ab2 = fma(g4, tap2, ab2);
-        absorb = fma(g3, tap3, absorb) + ab2;
-        if (is_null) absorb = 1.0;
         // (3) weights: process_qsos.m:192-198 folded into log_mvnpdf_low_rank.m:11-15
         const double r = fma(-absorb, pmu, py);
-        const double a2 = absorb * absorb;
-        const double d = fma(pom, a2, pnu);
-        const double inv_d = fast_rcp(d);
         const double w = a2 * inv_d;
         const double ri = r * inv_d;
         const double u = absorb * ri;

@@ -365,8 +365,31 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
         const double2 p23 = *reinterpret_cast<const double2 *>(mine + 2);
         const double py = p01.x, pmu = p01.y, pom = p23.x, pnu = p23.y;
         __builtin_amdgcn_sched_barrier(0);
+        // (2) instrument broadening for pixel 4 rn + jj: voigt.c:297-299 (symmetric taps).  In front of (1)
+        // since round 5: the three-line wing tier takes this pixel's d along and returns 1/d from the same
+        // v_rcp_f64 as its own three quotients (wing_sum3_rcp4): 151.06 -> 150.21 ms on one box
+        // (profiles/r05_ab_rcp4.txt), and the two spilled registers are gone.
+        double absorb = fma(g6, tap0, g0 * tap0);
+        {
+          double ab2 = fma(g5, tap1, g1 * tap1);
+          absorb = fma(g2, tap2, absorb);
+          ab2 = fma(g4, tap2, ab2);
+          absorb = fma(g3, tap3, absorb) + ab2;
+        }
+        if (is_null) absorb = 1.0;
+        const double a2 = absorb * absorb;
+        const double d = fma(pom, a2, pnu);
+        double inv_d;
         // (1) raw profile three K-steps ahead: voigt.c:282-292
-        const double total = optical_sum(lamP);
+        double total;
+        if constexpr (LINES == 3) {
+          bool near;
+          total = wing_sum3_rcp4(lamP, ms_r[0], ms_r[1], ms_r[2], cs, &near, d, &inv_d);
+          if (__builtin_expect(__any(near), 0)) total = total_near<3>(lamP, mult_r[0], mult_r[1], mult_r[2], nullptr, 3);
+        } else {
+          total = optical_sum(lamP);
+          inv_d = fast_rcp(d);
+        }
         const ExpState es = exp_ring_begin_scaled(nscale64 * total, exp_pad);
         __builtin_amdgcn_sched_barrier(0);
         double bop[14];
@@ -377,18 +400,8 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
         const double raw = exp_table_end_scaled(es);
         my_ring[slot_w] = raw;
         my_ring[slot_w + 16] = raw;
-        // (2) instrument broadening for pixel 4 rn + jj: voigt.c:297-299 (symmetric taps)
-        double absorb = fma(g6, tap0, g0 * tap0);
-        double ab2 = fma(g5, tap1, g1 * tap1);
-        absorb = fma(g2, tap2, absorb);
-        ab2 = fma(g4, tap2, ab2);
-        absorb = fma(g3, tap3, absorb) + ab2;
-        if (is_null) absorb = 1.0;
         // (3) weights: process_qsos.m:192-198 folded into log_mvnpdf_low_rank.m:11-15
         const double r = fma(-absorb, pmu, py);
-        const double a2 = absorb * absorb;
-        const double d = fma(pom, a2, pnu);
-        const double inv_d = fast_rcp(d);
         const double w = a2 * inv_d;
         const double ri = r * inv_d;
         const double u = absorb * ri;
