@@ -139,6 +139,10 @@ def test_shipped_kernels_have_no_dpp_hazard(shipped_isa, capsys):
     sweeps = {k: v for k, v in sizes.items() if "k_sweep" in k}
     assert len(sweeps) >= 10, sorted(sizes)
     assert max(sweeps.values()) <= 64, {k: v for k, v in sweeps.items() if v > 64}
+    # the headline kernel (three lines, k <= 20) keeps everything in registers since the K-step's two
+    # reciprocals became one (round 5): no scratch at all
+    headline = [v for k, v in sweeps.items() if "k_sweep_slimILi3" in k]
+    assert headline == [0], headline
 
 
 @needs_hipcc
