@@ -385,7 +385,9 @@ __global__ __launch_bounds__(512) void k_sweep_slim(SweepArgs a) {
         if constexpr (LINES == 3) {
           bool near;
           total = wing_sum3_rcp4(lamP, ms_r[0], ms_r[1], ms_r[2], cs, &near, d, &inv_d);
+#ifndef SLIM_EXP_NONEAR  // (ablation, results wrong by construction: what the accurate tier costs)
           if (__builtin_expect(__any(near), 0)) total = total_near<3>(lamP, mult_r[0], mult_r[1], mult_r[2], nullptr, 3);
+#endif
         } else {
           total = optical_sum(lamP);
           inv_d = fast_rcp(d);
